@@ -1,0 +1,137 @@
+/* sr355.h -- C ABI of libsr355.so: the MI355X (gfx950) super-resolution + defect-classifier hot path.
+ *
+ * The reference (bgmanuel99/Super-Resolution-Images-for-3D-Printing-Defect-Detection) has no
+ * FFI/plugin interface; its boundary to the device is the Keras call `model.predict(...)` /
+ * `generator(...)` / `tf.image.psnr|ssim` / `cv2.resize`.  Each entry point below names the
+ * reference call site (file:line under /root/reference) it stands in for.  The Python host
+ * (package sr355, mirroring the reference's SRModels/ classes) binds these with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - return 0 (SR_OK) on success, negative sr_status on error; text via sr_last_error(ctx).
+ *  - nothing throws across the ABI.
+ *  - image tensors are NHWC, dense, DEVICE pointers owned by the caller (e.g. torch tensors'
+ *    data_ptr()); conv kernels handed to sr_model_set_weight are HOST float32 HWIO, Dense [in,out].
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream) and
+ *    is asynchronous; the caller synchronises.
+ *  - one sr_ctx per GPU; a ctx (and its models) is not thread-safe; different ctxs are independent.
+ */
+#ifndef SR355_H
+#define SR355_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sr_ctx sr_ctx;
+typedef struct sr_model sr_model;
+
+typedef enum sr_status {
+    SR_OK = 0,
+    SR_ERR_INVALID = -1,   /* bad argument / unsupported shape                 */
+    SR_ERR_HIP = -2,       /* HIP runtime error (message holds hipGetErrorString) */
+    SR_ERR_OOM = -3,       /* device allocation failed                          */
+    SR_ERR_STATE = -4,     /* model not finalised / weight missing              */
+    SR_ERR_NAME = -5,      /* unknown layer name                                */
+    SR_ERR_CAPACITY = -6   /* caller's output buffer too small                  */
+} sr_status;
+
+enum { SR_DTYPE_F32 = 0, SR_DTYPE_BF16 = 1, SR_DTYPE_U8 = 2 };
+enum { SR_MODEL_SRCNN = 0, SR_MODEL_EDSR = 1, SR_MODEL_ESRGAN_G = 2, SR_MODEL_VGG16 = 3 };
+enum { SR_ACT_LINEAR = 0, SR_ACT_RELU = 1, SR_ACT_LRELU = 2, SR_ACT_TANH = 3 };
+enum { SR_WEIGHT_KERNEL = 0, SR_WEIGHT_BIAS = 1 };
+
+/* Architecture hyper-parameters = the keyword arguments of the reference's setup_model():
+ * SRCNN_model.py:23, EDSR_model.py:29, ESRGAN_model.py:108, VGG16_model.py:21. */
+typedef struct sr_model_cfg {
+    int32_t compute_dtype;    /* SR_DTYPE_F32 (reference precision) or SR_DTYPE_BF16 (fp32 accumulate) */
+    int32_t scale_factor;     /* EDSR: 2,3,4; ESRGAN: 2,4,8; ignored otherwise                         */
+    int32_t channels;         /* image channels (3)                                                    */
+    int32_t num_blocks;       /* EDSR num_res_blocks / ESRGAN num_rrdb_blocks                          */
+    int32_t num_filters;      /* EDSR num_filters (ESRGAN trunk is fixed at 64)                        */
+    int32_t growth_channels;  /* ESRGAN growth_channels                                                */
+    float   res_scaling;      /* EDSR res_scaling                                                      */
+    int32_t num_classes;      /* VGG16 classifier head width                                           */
+    int32_t use_attention;    /* ESRGAN: 1 = reference graph (two SelfAttention layers); 0 = tuning-only variant */
+} sr_model_cfg;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int  sr_init(int device_id, sr_ctx** out);
+void sr_destroy(sr_ctx* ctx);
+const char* sr_last_error(sr_ctx* ctx);
+/* bytes of device memory the library currently holds / has held at most (weights + workspaces).
+ * Feeds the reference's inference_metrics keys gpu_mean_current_mb / gpu_peak_mb
+ * (SRCNN_model.py:201-242, tf.config.experimental.get_memory_info). */
+int  sr_mem_info(sr_ctx* ctx, int64_t* current_bytes, int64_t* peak_bytes);
+/* wall-clock of the last sr_forward on this ctx measured with HIP events on its stream (ms);
+ * blocks until that forward has finished. */
+int  sr_last_forward_ms(sr_ctx* ctx, float* ms);
+
+/* ---- models: replaces Keras model build + predict ------------------------------------------ */
+/* Keras graph construction: SRCNN_model.py:45-53, EDSR_model.py:96-125, ESRGAN_model.py:303-345,
+ * VGG16_model.py:57-97. */
+int  sr_model_create(sr_ctx* ctx, int kind, const sr_model_cfg* cfg, sr_model** out);
+void sr_model_destroy(sr_model* m);
+/* number of parameter tensors the graph expects, and the i-th one's Keras layer name, which
+ * (kernel/bias) and shape (ndim <= 4).  Lets the host enumerate what load_model() would restore. */
+int  sr_model_num_params(sr_model* m);
+int  sr_model_param_info(sr_model* m, int index, const char** name, int* which, int64_t shape[4], int* ndim);
+/* copy one parameter (host fp32; conv HWIO, dense [in,out], bias [out]) into the model.
+ * Stands in for keras load_model / set_weights (SRCNN_model.py:35, ESRGAN_model.py:143-149). */
+int  sr_model_set_weight(sr_model* m, const char* keras_layer_name, int which,
+                         const float* host, const int64_t* shape, int ndim);
+/* pack all weights into the device MFMA layouts; must precede sr_forward. */
+int  sr_model_finalize(sr_model* m);
+/* output shape for an input of [B,H,W,C]. */
+int  sr_model_output_shape(sr_model* m, int B, int H, int W, int C, int64_t out_shape[4]);
+/* model.predict / generator(x): SRCNN_model.py:210, EDSR_model.py:274, ESRGAN_model.py:941,
+ * VGG16_model.py:244.  x,y DEVICE NHWC of `io_dtype` (f32 or bf16; VGG16 output is [B,num_classes]).
+ * y_capacity in elements. */
+int  sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, int C,
+                void* y, int64_t y_capacity, void* stream);
+
+/* ---- single ops (also used by the kernel-level parity tests) -------------------------------- */
+/* Keras Conv2D(padding="same", strides=1) + bias + activation, then
+ * y = alpha*act(conv+b) + beta1*skip1 + beta2*skip2, optional clip[0,1], optional depth_to_space(r)
+ * in TF "DCR" order (EDSR_model.py:61-90, ESRGAN_model.py:230-299).  x [B,H,W,Cin], w HOST HWIO,
+ * skips [B,H,W,Cout] (same dtype as x), y [B,H*r,W*r,Cout/r^2].  dtype applies to x, skips and y. */
+int  sr_conv2d(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int Cin,
+               const float* w_hwio, const float* bias, int KH, int KW, int Cout, int act,
+               float alpha, const void* skip1, float beta1, const void* skip2, float beta2,
+               int clip01, int d2s_r, void* y, void* stream);
+/* SelfAttention.call (ESRGAN_model.py:48-70) on x [B,H,W,C]; weights HOST HWIO 1x1. */
+int  sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C,
+                       const float* wf, const float* bf, const float* wg, const float* bg,
+                       const float* wh, const float* bh, const float* wv, const float* bv,
+                       void* y, void* stream);
+/* cv2.resize(..., interpolation=cv2.INTER_CUBIC) (classic_algorithms.py:11-13, SRCNN_model.py:191,
+ * loading_methods.py:147).  dtype f32: float path; u8: OpenCV fixed-point path. */
+int  sr_bicubic(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C,
+                int outH, int outW, void* y, void* stream);
+/* tf.image.psnr / tf.image.ssim(max_val) (metrics.py:3-7): a,b f32 [B,H,W,C] -> out f32 [B] (device). */
+int  sr_psnr(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float max_val,
+             float* out_B, void* stream);
+int  sr_ssim(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float max_val,
+             float* out_B, void* stream);
+/* mean squared error over all elements -> out f32 [1] (Keras loss="mean_squared_error",
+ * SRCNN_model.py:59). */
+int  sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream);
+/* add_padding + sliding-window extraction (SRCNN_model.py:127-162, EDSR_model.py:201-223,
+ * ESRGAN_model.py:883-901, VGG16_model.py:216-239): img f32 [H,W,C] (unpadded), reflect padding
+ * bottom/right computed from (patch,stride); out [P,patch,patch,C] of out_dtype, each value
+ * v*mul+add (ESRGAN: *2-1).  *n_patches receives P.  out may be NULL to query P only. */
+int  sr_extract_patches(sr_ctx* ctx, const float* img, int H, int W, int C, int patch, int stride,
+                        float mul, float add, int out_dtype, void* out, int64_t out_capacity,
+                        int* n_patches, void* stream);
+/* reconstruct_from_patches (SRCNN_model.py:164-188, EDSR_model.py:225-256, ESRGAN_model.py:903-921):
+ * overlap-add of [P,patch*scale,patch*scale,C] patches (in_dtype; value v*mul+add first, ESRGAN:
+ * (v+1)/2), divide by coverage count, crop to [H*scale,W*scale,C], clip[0,1]; out f32.
+ * H,W = unpadded LR size; patch,stride in LR pixels. */
+int  sr_overlap_add(sr_ctx* ctx, const void* patches, int in_dtype, int H, int W, int C, int patch,
+                    int stride, int scale, float mul, float add, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR355_H */

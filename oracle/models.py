@@ -1,0 +1,220 @@
+"""Oracle model graphs (CPU).  TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+Restates the Keras graphs the reference builds; weights are dicts
+{keras_layer_name: (kernel, bias)} with conv kernels HWIO and Dense kernels [in,out]
+(SURVEY.md Appendix D).  Layer names follow the reference where it names them
+(ESRGAN_model.py:230-341) and Keras auto-naming order otherwise.
+"""
+import numpy as np
+
+from . import ops
+
+VGG16_CFG = [(1, 2, 64), (2, 2, 128), (3, 3, 256), (4, 3, 512), (5, 3, 512)]
+VGG19_CFG = [(1, 2, 64), (2, 2, 128), (3, 4, 256), (4, 4, 512), (5, 4, 512)]
+
+
+# ---------------------------------------------------------------- layer tables (name, shape)
+def srcnn_layers(channels=3):
+    """SRCNN_model.py:48-53: 9x9x96 relu, 1x1x32 relu, 5x5x3 linear."""
+    return [("conv2d", (9, 9, channels, 96)), ("conv2d_1", (1, 1, 96, 32)), ("conv2d_2", (5, 5, 32, channels))]
+
+
+def edsr_layers(scale=2, channels=3, num_res_blocks=16, num_filters=64):
+    """EDSR_model.py:96-125 in construction order (Keras auto names conv2d, conv2d_1, ...)."""
+    shapes = [(3, 3, channels, num_filters)]
+    for _ in range(num_res_blocks):
+        shapes += [(3, 3, num_filters, num_filters)] * 2
+    shapes.append((3, 3, num_filters, num_filters))
+    if scale == 2:
+        shapes.append((3, 3, num_filters, num_filters * 4))
+    elif scale == 3:
+        shapes.append((3, 3, num_filters, num_filters * 9))
+    elif scale == 4:
+        shapes += [(3, 3, num_filters, num_filters * 4)] * 2
+    else:
+        raise ValueError(f"Scale factor {scale} not supported. Use 2, 3, or 4.")
+    shapes.append((3, 3, num_filters, channels))
+    return [("conv2d" if i == 0 else f"conv2d_{i}", s) for i, s in enumerate(shapes)]
+
+
+def self_attention_layers(name, channels=64):
+    """ESRGAN_model.py:41-44."""
+    return [(f"{name}_f", (1, 1, channels, channels // 8)), (f"{name}_g", (1, 1, channels, channels // 8)),
+            (f"{name}_h", (1, 1, channels, channels // 2)), (f"{name}_v", (1, 1, channels // 2, channels))]
+
+
+def esrgan_g_layers(scale=2, growth=32, num_rrdb=23, channels=3):
+    """ESRGAN_model.py:303-345."""
+    L = [("initial_conv", (3, 3, channels, 64))]
+    for b in range(num_rrdb):
+        for d in (1, 2, 3):
+            for k in range(1, 5):
+                L.append((f"rrdb_{b}_dense{d}_conv{k}", (3, 3, 64 + (k - 1) * growth, growth)))
+            L.append((f"rrdb_{b}_dense{d}_conv5", (3, 3, 64 + 4 * growth, 64)))
+    L.append(("trunk_conv", (3, 3, 64, 64)))
+    L += self_attention_layers("self_attention_trunk")
+    for i in range(int(np.log2(scale))):
+        L.append((f"upsample_{i}_conv", (3, 3, 64, 256)))
+        if i == 0:
+            L += self_attention_layers("self_attention_upsample_0")
+    L += [("final_conv1", (3, 3, 64, 64)), ("final_conv2", (3, 3, 64, channels))]
+    return L
+
+
+def vgg_base_layers(cfg, channels=3):
+    L, cin = [], channels
+    for blk, n, f in cfg:
+        for k in range(1, n + 1):
+            L.append((f"block{blk}_conv{k}", (3, 3, cin, f)))
+            cin = f
+    return L
+
+
+def vgg16_classifier_layers(num_classes=2):
+    """VGG16_model.py:69-97: VGG16 base (no top) -> GAP -> Dense256 relu -> Dense(num_classes) softmax."""
+    return vgg_base_layers(VGG16_CFG) + [("dense", (512, 256)), ("predictions", (256, num_classes))]
+
+
+def discriminator_layers():
+    """ESRGAN_model.py:347-377 (for the parameter-count pin only; training is a later row)."""
+    L = [("disc_conv1", (3, 3, 3, 64))]
+    cin = 64
+    for i, f in enumerate([64, 64, 128, 128, 256]):
+        L.append((f"disc_conv{i + 2}", (3, 3, cin, f)))
+        cin = f
+    return L + [("disc_dense1", (256, 256)), ("disc_output", (256, 1))]
+
+
+def count_params(layers):
+    return int(sum(int(np.prod(s)) + s[-1] for _, s in layers))
+
+
+# ---------------------------------------------------------------- forwards
+def srcnn_forward(x, w, dtype=np.float32):
+    x = ops.conv2d(x, *w["conv2d"], act="relu", dtype=dtype)
+    x = ops.conv2d(x, *w["conv2d_1"], act="relu", dtype=dtype)
+    return ops.conv2d(x, *w["conv2d_2"], dtype=dtype)
+
+
+def edsr_forward(x, w, scale=2, num_res_blocks=16, res_scaling=0.1, dtype=np.float32):
+    names = ["conv2d"] + [f"conv2d_{i}" for i in range(1, 2 * num_res_blocks + 5)]
+    it = iter(names)
+    x = ops.conv2d(x, *w[next(it)], dtype=dtype)
+    head = x
+    for _ in range(num_res_blocks):
+        sc = x
+        x = ops.conv2d(x, *w[next(it)], act="relu", dtype=dtype)
+        x = ops.conv2d(x, *w[next(it)], dtype=dtype)
+        if res_scaling != 1.0:
+            x = x * dtype(res_scaling)
+        x = x + sc
+    x = ops.conv2d(x, *w[next(it)], dtype=dtype) + head
+    if scale in (2, 3):
+        x = ops.depth_to_space(ops.conv2d(x, *w[next(it)], dtype=dtype), scale)
+    elif scale == 4:
+        x = ops.depth_to_space(ops.conv2d(x, *w[next(it)], dtype=dtype), 2)
+        x = ops.depth_to_space(ops.conv2d(x, *w[next(it)], dtype=dtype), 2)
+    else:
+        raise ValueError(scale)
+    x = ops.conv2d(x, *w[next(it)], dtype=dtype)
+    return np.clip(x, 0.0, 1.0)
+
+
+def _dense_block(x, w, name, dtype):
+    """ESRGAN_model.py:212-254."""
+    feats = [x]
+    for k in range(1, 5):
+        feats.append(ops.conv2d(np.concatenate(feats, axis=-1), *w[f"{name}_conv{k}"], act="relu", dtype=dtype))
+    x5 = ops.conv2d(np.concatenate(feats, axis=-1), *w[f"{name}_conv5"], dtype=dtype)
+    return x + x5 * dtype(0.2)
+
+
+def _sa(x, w, name, dtype, parts=None):
+    r = ops.self_attention(x, *w[f"{name}_f"], *w[f"{name}_g"], *w[f"{name}_h"], *w[f"{name}_v"], dtype=dtype,
+                           return_parts=parts is not None)
+    if parts is not None:
+        parts[name] = r[1]
+        return r[0]
+    return r
+
+
+def esrgan_g_forward(x, w, scale=2, num_rrdb=23, dtype=np.float32, attention=True, parts=None):
+    """ESRGAN_model.py:303-345.  x in [-1,1]; output tanh in [-1,1]."""
+    x = ops.conv2d(x, *w["initial_conv"], dtype=dtype)
+    trunk = x
+    for b in range(num_rrdb):
+        r_in = x
+        for d in (1, 2, 3):
+            x = _dense_block(x, w, f"rrdb_{b}_dense{d}", dtype)
+        x = r_in + x * dtype(0.2)
+    x = trunk + ops.conv2d(x, *w["trunk_conv"], dtype=dtype)
+    if parts is not None:
+        parts["trunk_add"] = x
+    if attention:
+        x = _sa(x, w, "self_attention_trunk", dtype, parts)
+    for i in range(int(np.log2(scale))):
+        x = ops.conv2d(x, *w[f"upsample_{i}_conv"], dtype=dtype)
+        x = ops.activation(ops.depth_to_space(x, 2), "lrelu")
+        if i == 0 and attention:
+            x = _sa(x, w, "self_attention_upsample_0", dtype, parts)
+    x = ops.conv2d(x, *w["final_conv1"], act="relu", dtype=dtype)
+    return ops.conv2d(x, *w["final_conv2"], act="tanh", dtype=dtype)
+
+
+def vgg16_features(x, w, cfg=VGG16_CFG, dtype=np.float32):
+    for blk, n, _ in cfg:
+        for k in range(1, n + 1):
+            x = ops.conv2d(x, *w[f"block{blk}_conv{k}"], act="relu", dtype=dtype)
+        x = ops.maxpool2x2(x)
+    return x
+
+
+def vgg16_classifier_forward(x, w, dtype=np.float32):
+    """VGG16_model.py:84-97; inputs are [0,1] floats with NO ImageNet preprocessing; Dropout is
+    identity at inference."""
+    f = vgg16_features(x, w, dtype=dtype)
+    g = f.mean(axis=(1, 2), dtype=dtype)
+    h = ops.dense(g, *w["dense"], act="relu", dtype=dtype)
+    return ops.dense(h, *w["predictions"], act="softmax", dtype=dtype)
+
+
+# ---------------------------------------------------------------- pipelines (super_resolve_image etc.)
+def srcnn_super_resolve(lr_img, w, hr_h, hr_w, patch_size=33, stride=14, dtype=np.float32):
+    """SRCNN_model.py:111-247 (bicubic pre-upscale, no clip, patches at HR resolution)."""
+    up = ops.bicubic_resize(lr_img, hr_h, hr_w)
+    padded = ops.add_padding(up, patch_size, stride)
+    patches, pos = ops.extract_patches(padded, patch_size, stride)
+    preds = srcnn_forward(patches, w, dtype=dtype)
+    return ops.overlap_add(preds, pos, padded.shape, up.shape[:2], patch_size, 1)
+
+
+def edsr_super_resolve(lr_img, w, scale, patch_size_lr=48, stride=24, num_res_blocks=16, res_scaling=0.1,
+                       dtype=np.float32):
+    """EDSR_model.py:189-315."""
+    padded = ops.add_padding(np.asarray(lr_img, np.float32), patch_size_lr, stride)
+    patches, pos = ops.extract_patches(padded, patch_size_lr, stride)
+    preds = edsr_forward(patches, w, scale, num_res_blocks, res_scaling, dtype=dtype)
+    return ops.overlap_add(preds, pos, padded.shape, lr_img.shape[:2], patch_size_lr, scale)
+
+
+def esrgan_super_resolve(lr_img, w, scale, patch_size_lr=48, stride=24, num_rrdb=23, dtype=np.float32,
+                         chunk=16, attention=True):
+    """ESRGAN_model.py:858-979 ([0,1] -> [-1,1] in, (out+1)/2 back)."""
+    padded = ops.add_padding(np.asarray(lr_img, np.float32), patch_size_lr, stride)
+    patches, pos = ops.extract_patches(padded, patch_size_lr, stride)
+    x = patches * 2.0 - 1.0
+    outs = [esrgan_g_forward(x[i:i + chunk], w, scale, num_rrdb, dtype=dtype, attention=attention)
+            for i in range(0, len(x), chunk)]
+    hr = (np.concatenate(outs, axis=0).astype(np.float32) + 1.0) / 2.0
+    return ops.overlap_add(hr, pos, padded.shape, lr_img.shape[:2], patch_size_lr, scale)
+
+
+def classify_defects(image, w, patch_size=96, stride=None, dtype=np.float32):
+    """VGG16_model.py:168-270."""
+    img = np.asarray(image)
+    if stride is None:
+        stride = max(1, patch_size // 2)
+    ph, pw = ops.pad_amount(img.shape[0], patch_size, stride), ops.pad_amount(img.shape[1], patch_size, stride)
+    padded = img if (ph == 0 and pw == 0) else ops.add_padding(img, patch_size, stride)
+    patches, _ = ops.extract_patches(padded, patch_size, stride)
+    return ops.majority_vote(vgg16_classifier_forward(patches, w, dtype=dtype))

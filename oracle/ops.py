@@ -1,0 +1,369 @@
+"""Oracle primitive ops (CPU, torch/NumPy).  TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+All image tensors are NHWC, conv kernels HWIO, Dense kernels [in, out] (the reference's
+Keras/TensorFlow conventions).  Functions accept and return NumPy
+arrays; `dtype` selects the arithmetic precision (np.float32 or np.float64).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(x, dtype):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=dtype)))
+
+
+# --------------------------------------------------------------------------------------
+# Activations (Keras semantics)
+# --------------------------------------------------------------------------------------
+def activation(x, act):
+    """act in {None/'linear','relu','lrelu','tanh','sigmoid'}; LeakyReLU alpha=0.2
+    (reference: ESRGAN_model.py:299)."""
+    if act in (None, "linear", "none"):
+        return x
+    if act == "relu":
+        return np.maximum(x, 0)
+    if act == "lrelu":
+        return np.where(x > 0, x, x * np.asarray(0.2, dtype=x.dtype))
+    if act == "tanh":
+        return np.tanh(x)
+    if act == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-x))
+    raise ValueError(act)
+
+
+# --------------------------------------------------------------------------------------
+# Conv2D, Keras padding="same" / "valid" 
+# --------------------------------------------------------------------------------------
+def same_pads(in_size, k, stride):
+    """TF SAME padding: out=ceil(in/stride); total=max((out-1)*stride+k-in,0);
+    before=total//2, after=total-before (extra pixel bottom/right)."""
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + k - in_size, 0)
+    return total // 2, total - total // 2
+
+
+def conv2d(x, w, b=None, stride=1, padding="same", act=None, dtype=np.float32):
+    """y = act(x (*) w + b): cross-correlation, x NHWC, w HWIO.
+    Reference call sites: SRCNN_model.py:50-52, EDSR_model.py:61-121,
+    ESRGAN_model.py:230-341 (Keras Conv2D)."""
+    x = np.asarray(x, dtype=dtype)
+    w = np.asarray(w, dtype=dtype)
+    kh, kw = w.shape[:2]
+    xt = _t(x, dtype).permute(0, 3, 1, 2)
+    wt = _t(w, dtype).permute(3, 2, 0, 1)
+    if padding == "same":
+        pt, pb = same_pads(x.shape[1], kh, stride)
+        pl, pr = same_pads(x.shape[2], kw, stride)
+        xt = F.pad(xt, (pl, pr, pt, pb))
+    elif padding != "valid":
+        raise ValueError(padding)
+    bt = None if b is None else _t(b, dtype)
+    y = F.conv2d(xt, wt, bt, stride=stride).permute(0, 2, 3, 1).contiguous().numpy()
+    return activation(y, act)
+
+
+def conv2d_naive(x, w, b=None, stride=1, padding="same"):
+    """Independent second derivation: plain fp64 NumPy loops over taps (small cases only)."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    B, H, W, C = x.shape
+    kh, kw, _, O = w.shape
+    if padding == "same":
+        pt, pb = same_pads(H, kh, stride)
+        pl, pr = same_pads(W, kw, stride)
+        x = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    Ho = (x.shape[1] - kh) // stride + 1
+    Wo = (x.shape[2] - kw) // stride + 1
+    y = np.zeros((B, Ho, Wo, O))
+    for i in range(kh):
+        for j in range(kw):
+            xs = x[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :]
+            y += np.einsum("bhwc,co->bhwo", xs, w[i, j])
+    if b is not None:
+        y += np.asarray(b, dtype=np.float64)
+    return y
+
+
+def dense(x, w, b=None, act=None, dtype=np.float32):
+    """Keras Dense: y = x @ W + b, W [in,out] (VGG16_model.py:90-96)."""
+    y = np.asarray(x, dtype=dtype) @ np.asarray(w, dtype=dtype)
+    if b is not None:
+        y = y + np.asarray(b, dtype=dtype)
+    if act == "softmax":
+        y = y - y.max(axis=-1, keepdims=True)
+        e = np.exp(y)
+        return e / e.sum(axis=-1, keepdims=True)
+    return activation(y, act)
+
+
+# --------------------------------------------------------------------------------------
+# depth_to_space, TF "DCR" channel order
+# --------------------------------------------------------------------------------------
+def depth_to_space(x, r):
+    """out[b, h*r+i, w*r+j, c] = in[b, h, w, (i*r + j)*C + c]
+    (tf.nn.depth_to_space NHWC; EDSR_model.py:81-90, ESRGAN_model.py:298)."""
+    B, H, W, Cr = x.shape
+    C = Cr // (r * r)
+    y = x.reshape(B, H, W, r, r, C)          # [b,h,w,i,j,c]
+    y = y.transpose(0, 1, 3, 2, 4, 5)        # [b,h,i,w,j,c]
+    return np.ascontiguousarray(y.reshape(B, H * r, W * r, C))
+
+
+def maxpool2x2(x):
+    """Keras MaxPooling2D(2,2) VALID (floor)."""
+    B, H, W, C = x.shape
+    Ho, Wo = H // 2, W // 2
+    x = x[:, :Ho * 2, :Wo * 2, :].reshape(B, Ho, 2, Wo, 2, C)
+    return x.max(axis=(2, 4))
+
+
+# --------------------------------------------------------------------------------------
+# SelfAttention (ESRGAN_model.py:48-70): no 1/sqrt(d) scale, no gamma gate
+# --------------------------------------------------------------------------------------
+def self_attention(x, wf, bf, wg, bg, wh, bh, wv, bv, dtype=np.float32, return_parts=False):
+    """f,g = 1x1 conv -> C/8; h = 1x1 -> C/2; s = g . f^T  [B,N,N]; beta = softmax(s,-1);
+    o = beta . h; o = 1x1 conv -> C; y = x + o."""
+    x = np.asarray(x, dtype=dtype)
+    B, H, W, C = x.shape
+    f = conv2d(x, wf, bf, dtype=dtype).reshape(B, H * W, -1)
+    g = conv2d(x, wg, bg, dtype=dtype).reshape(B, H * W, -1)
+    h = conv2d(x, wh, bh, dtype=dtype).reshape(B, H * W, -1)
+    s = np.einsum("bnd,bmd->bnm", g, f)                      # g rows (queries), f cols (keys)
+    s = s - s.max(axis=-1, keepdims=True)
+    e = np.exp(s)
+    beta = e / e.sum(axis=-1, keepdims=True)
+    o = np.einsum("bnm,bmd->bnd", beta, h).reshape(B, H, W, -1).astype(dtype)
+    ov = conv2d(o, wv, bv, dtype=dtype)
+    y = x + ov
+    if return_parts:
+        return y, dict(f=f, g=g, h=h, o=o)
+    return y
+
+
+def attention_rows_streaming(q_rows, k, v):
+    """fp64 streaming-softmax oracle for sampled query rows (whole-tile attention cannot be
+    materialised: SURVEY.md 8d).  q_rows [R,d], k [N,d], v [N,dv] -> [R,dv]."""
+    q_rows = np.asarray(q_rows, np.float64)
+    k = np.asarray(k, np.float64)
+    v = np.asarray(v, np.float64)
+    out = np.zeros((q_rows.shape[0], v.shape[1]))
+    m = np.full(q_rows.shape[0], -np.inf)
+    l = np.zeros(q_rows.shape[0])
+    step = 65536
+    for s0 in range(0, k.shape[0], step):
+        s = q_rows @ k[s0:s0 + step].T
+        mn = np.maximum(m, s.max(axis=1))
+        a = np.exp(m - mn)
+        p = np.exp(s - mn[:, None])
+        l = l * a + p.sum(axis=1)
+        out = out * a[:, None] + p @ v[s0:s0 + step]
+        m = mn
+    return out / l[:, None]
+
+
+# --------------------------------------------------------------------------------------
+# Bicubic resize, OpenCV INTER_CUBIC semantics
+# reference call sites: classic_algorithms.py:11-13, SRCNN_model.py:191, loading_methods.py:147
+# --------------------------------------------------------------------------------------
+_CUBIC_A = -0.75
+
+
+def cubic_coeffs(fx, dtype=np.float32):
+    """OpenCV interpolateCubic: three Keys(a=-0.75) polynomials, fourth = 1 - sum."""
+    A = dtype(_CUBIC_A)
+    x = np.asarray(fx, dtype=dtype)
+    one = dtype(1)
+    c0 = ((A * (x + one) - dtype(5) * A) * (x + one) + dtype(8) * A) * (x + one) - dtype(4) * A
+    c1 = ((A + dtype(2)) * x - (A + dtype(3))) * x * x + one
+    c2 = ((A + dtype(2)) * (one - x) - (A + dtype(3))) * (one - x) * (one - x) + one
+    c3 = one - c0 - c1 - c2
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(dtype)
+
+
+def _cubic_axis(n_src, n_dst, dtype):
+    """Per destination index: 4 clamped source indices and 4 weights (half-pixel centres,
+    replicate border)."""
+    scale = 1.0 / (float(n_dst) / float(n_src))                 # OpenCV: scale = 1/inv_scale, double
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)            # (float)((dx+0.5)*scale_x - 0.5)
+    s = np.floor(f).astype(np.int64)
+    frac = (f - s.astype(np.float32)).astype(np.float32)
+    idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+    return idx, cubic_coeffs(frac.astype(dtype), dtype)
+
+
+def bicubic_resize(img, out_h, out_w, dtype=np.float32):
+    """Float path of cv2.resize(img, (out_w, out_h), interpolation=INTER_CUBIC): horizontal
+    pass then vertical pass, no clipping.  img [H,W,C] or [B,H,W,C] float."""
+    img = np.asarray(img, dtype=dtype)
+    squeeze = img.ndim == 3
+    if squeeze:
+        img = img[None]
+    B, H, W, C = img.shape
+    ix, wx = _cubic_axis(W, out_w, dtype)
+    iy, wy = _cubic_axis(H, out_h, dtype)
+    tmp = np.zeros((B, H, out_w, C), dtype=dtype)
+    for k in range(4):
+        tmp += img[:, :, ix[:, k], :] * wx[None, None, :, k, None]
+    out = np.zeros((B, out_h, out_w, C), dtype=dtype)
+    for k in range(4):
+        out += tmp[:, iy[:, k], :, :] * wy[None, :, k, None, None]
+    return out[0] if squeeze else out
+
+
+def bicubic_resize_u8(img, out_h, out_w):
+    """uint8 path of cv2.resize INTER_CUBIC: 11-bit fixed-point coefficients
+    (INTER_RESIZE_COEF_BITS=11), int32 accumulation, rounding shift by 22, saturate
+    (super_resolucion_clasica.ipynb cell 7 feeds uint8)."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8
+    H, W, C = img.shape
+    ix, wx = _cubic_axis(W, out_w, np.float32)
+    iy, wy = _cubic_axis(H, out_h, np.float32)
+    iwx = np.clip(np.rint(wx * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    iwy = np.clip(np.rint(wy * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    src = img.astype(np.int64)
+    tmp = np.zeros((H, out_w, C), dtype=np.int64)
+    for k in range(4):
+        tmp += src[:, ix[:, k], :] * iwx[None, :, k, None]
+    out = np.zeros((out_h, out_w, C), dtype=np.int64)
+    for k in range(4):
+        out += tmp[iy[:, k], :, :] * iwy[:, k, None, None]
+    out = (out + (1 << 21)) >> 22
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
+# PSNR / SSIM, tf.image semantics (reference metrics.py:3-7)
+# --------------------------------------------------------------------------------------
+def psnr(a, b, max_val=1.0, dtype=np.float32):
+    """Per-image: 20*log10(max) - 10*log10(mean((a-b)^2 over H,W,C)); mse=0 -> +inf."""
+    a = np.asarray(a, dtype=dtype)
+    b = np.asarray(b, dtype=dtype)
+    mse = np.mean((a - b) ** 2, axis=(-3, -2, -1), dtype=dtype)
+    with np.errstate(divide="ignore"):
+        return (dtype(20.0) * np.log10(dtype(max_val)) - dtype(10.0) * np.log10(mse)).astype(dtype)
+
+
+def gauss_kernel_1d(size=11, sigma=1.5, dtype=np.float64):
+    """1-D factor of tf.image's _fspecial_gauss: softmax over -(x^2)/(2 sigma^2), x=-5..5.
+    The 2-D 121-entry softmax is exactly the outer product of this vector with itself."""
+    x = np.arange(size, dtype=np.float64) - (size - 1) / 2.0
+    g = np.exp(-(x ** 2) / (2.0 * sigma * sigma))
+    return (g / g.sum()).astype(dtype)
+
+
+def ssim(a, b, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03, dtype=np.float32):
+    """tf.image.ssim: 11x11 gaussian depthwise VALID filtering, per channel
+    lum*cs averaged over space, then over channels.  a,b [B,H,W,C] (or [H,W,C])."""
+    a = np.asarray(a, dtype=dtype)
+    b = np.asarray(b, dtype=dtype)
+    squeeze = a.ndim == 3
+    if squeeze:
+        a, b = a[None], b[None]
+    if a.shape[1] < filter_size or a.shape[2] < filter_size:
+        raise ValueError("ssim needs H,W >= filter_size")
+    g1 = gauss_kernel_1d(filter_size, filter_sigma, np.float64)
+    g2 = np.outer(g1, g1)
+    C = a.shape[-1]
+    wt = _t(np.broadcast_to(g2[None, None], (C, 1, filter_size, filter_size)).copy(), dtype)
+
+    def red(x):
+        return F.conv2d(_t(x, dtype).permute(0, 3, 1, 2), wt, groups=C).permute(0, 2, 3, 1).numpy()
+
+    c1 = dtype((k1 * max_val) ** 2)
+    c2 = dtype((k2 * max_val) ** 2)
+    m0, m1 = red(a), red(b)
+    num0 = m0 * m1 * dtype(2.0)
+    den0 = m0 * m0 + m1 * m1
+    lum = (num0 + c1) / (den0 + c1)
+    num1 = red(a * b) * dtype(2.0)
+    den1 = red(a * a + b * b)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    val = np.mean(lum * cs, axis=(1, 2), dtype=dtype)        # [B,C]
+    out = np.mean(val, axis=-1, dtype=dtype).astype(dtype)
+    return out[0] if squeeze else out
+
+
+def ssim_naive(a, b, max_val=1.0):
+    """Independent second derivation of tf.image.ssim in fp64 via scipy separable filters."""
+    from scipy.ndimage import correlate1d
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    g = gauss_kernel_1d(11, 1.5, np.float64)
+
+    def red(x):  # x [H,W,C], VALID
+        y = correlate1d(x, g, axis=0, mode="constant")
+        y = correlate1d(y, g, axis=1, mode="constant")
+        return y[5:-5, 5:-5, :]
+
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    res = []
+    for i in range(a.shape[0]):
+        m0, m1 = red(a[i]), red(b[i])
+        lum = (2 * m0 * m1 + c1) / (m0 ** 2 + m1 ** 2 + c1)
+        cs = (2 * red(a[i] * b[i]) - 2 * m0 * m1 + c2) / (red(a[i] ** 2 + b[i] ** 2) - m0 ** 2 - m1 ** 2 + c2)
+        res.append((lum * cs).mean(axis=(0, 1)).mean())
+    return np.asarray(res)
+
+
+# --------------------------------------------------------------------------------------
+# Patch plumbing (loading_methods.py:6-26; SRCNN_model.py:127-188; EDSR_model.py:201-256;
+# ESRGAN_model.py:883-921; VGG16_model.py:216-239)
+# --------------------------------------------------------------------------------------
+def pad_amount(n, patch, stride):
+    """pad = (p - n%s)%s if n%s else 0; pad = max(pad, p - s)   (loading_methods.py:12-17)."""
+    pad = (patch - (n % stride)) % stride if n % stride != 0 else 0
+    return max(pad, patch - stride)
+
+
+def add_padding(image, patch, stride):
+    """Reflect padding (np.pad mode='reflect': mirror without repeating the edge sample),
+    bottom and right only (loading_methods.py:20-24)."""
+    h, w = image.shape[:2]
+    return np.pad(image, ((0, pad_amount(h, patch, stride)), (0, pad_amount(w, patch, stride)), (0, 0)),
+                  mode="reflect")
+
+
+def patch_positions(h, w, patch, stride):
+    return [(i, j) for i in range(0, h - patch + 1, stride) for j in range(0, w - patch + 1, stride)]
+
+
+def extract_patches(image, patch, stride):
+    pos = patch_positions(image.shape[0], image.shape[1], patch, stride)
+    if not pos:
+        return np.empty((0, patch, patch, image.shape[2]), dtype=np.float32), pos
+    return np.asarray([image[i:i + patch, j:j + patch, :] for i, j in pos], dtype=np.float32), pos
+
+
+def overlap_add(patches, positions, padded_hw, out_hw, patch, scale=1):
+    """Scatter-add patches + count, divide (0 where count==0), crop, clip[0,1]
+    (SRCNN_model.py:164-188, EDSR_model.py:225-256)."""
+    hp, wp = padded_hw[0] * scale, padded_hw[1] * scale
+    ps = patch * scale
+    rec = np.zeros((hp, wp, 3), dtype=np.float32)
+    cnt = np.zeros((hp, wp, 3), dtype=np.float32)
+    for p, (i, j) in zip(patches, positions):
+        rec[i * scale:i * scale + ps, j * scale:j * scale + ps, :] += p
+        cnt[i * scale:i * scale + ps, j * scale:j * scale + ps, :] += 1.0
+    rec = np.divide(rec, cnt, out=np.zeros_like(rec), where=cnt != 0)
+    return np.clip(rec[:out_hw[0] * scale, :out_hw[1] * scale, :], 0.0, 1.0)
+
+
+def majority_vote(probs):
+    """VGG16_model.py:252-268: argmax per patch, bincount, tie -> highest mean prob among the
+    tied classes, confidence = mean prob of the winner."""
+    probs = np.asarray(probs)
+    if probs.ndim != 2:
+        probs = probs.reshape((probs.shape[0], -1))
+    nc = int(probs.shape[1])
+    votes = np.bincount(np.argmax(probs, axis=1), minlength=nc)
+    top = np.where(votes == votes.max())[0]
+    if len(top) == 1:
+        win = int(top[0])
+    else:
+        win = int(top[np.argmax(probs.mean(axis=0)[top])])
+    return win, float(probs[:, win].mean())

@@ -1,0 +1,640 @@
+// api.hip -- the C ABI of libsr355.so (include/sr355.h) and the model graphs behind sr_forward.
+//
+// A model is a flat list of ops over numbered NHWC activation buffers, built once from the
+// reference's hyper-parameters (SRCNN_model.py:45-53, EDSR_model.py:96-125, ESRGAN_model.py:303-345,
+// VGG16_model.py:57-97).  All fusion decisions live here:
+//   * bias/activation/residual-scale/skip adds/clip/depth_to_space ride in the conv epilogue;
+//   * an ESRGAN dense block is a "virtual concat": one 64+4G-channel buffer, conv k reads channels
+//     [0, 64+(k-1)G) and writes [64+(k-1)G, 64+kG); conv5 writes x + 0.2*conv into channels [0,64) of
+//     the next block's buffer (three buffers rotate so the RRDB input survives for the outer skip);
+//   * SelfAttention = one 1x1 conv producing f|g|h side by side, the streaming-softmax kernel, and
+//     the 1x1 "v" conv with the residual add in its epilogue.
+#include <math.h>
+#include <string.h>
+
+#include <memory>
+
+#include "common.h"
+
+// =================================================================================================
+// ctx
+// =================================================================================================
+void* sr_ctx::dalloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+        return nullptr;
+    }
+    allocs[p] = bytes;
+    cur_bytes += (int64_t)bytes;
+    if (cur_bytes > peak_bytes) peak_bytes = cur_bytes;
+    return p;
+}
+void sr_ctx::dfree(void* p) {
+    if (!p) return;
+    auto it = allocs.find(p);
+    if (it != allocs.end()) { cur_bytes -= (int64_t)it->second; allocs.erase(it); }
+    (void)hipFree(p);
+}
+void* sr_ctx::scratch(size_t bytes) {
+    if (bytes <= scratch_cap) return scratch_buf;
+    if (scratch_buf) { (void)hipDeviceSynchronize(); dfree(scratch_buf); scratch_buf = nullptr; scratch_cap = 0; }
+    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+    scratch_buf = dalloc(cap);
+    if (scratch_buf) scratch_cap = cap;
+    return scratch_buf;
+}
+
+// =================================================================================================
+// model graph
+// =================================================================================================
+namespace {
+
+struct Param {
+    std::string name; int which; std::vector<int64_t> shape; std::vector<float> host; bool set = false;
+    int64_t count() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+struct Ref { int buf = -1; int coff = 0; };        // buf: >=0 internal, -1 none, -2 caller's y
+enum OpKind { OP_CONVERT, OP_CONV, OP_ATTN, OP_POOL, OP_GAP, OP_DENSE };
+struct Op {
+    OpKind kind = OP_CONV;
+    Ref in, out, skip1, skip2;
+    int conv = -1;
+    int act = SR_ACT_LINEAR; float alpha = 1.f, beta1 = 0.f, beta2 = 0.f; int clip = 0, d2s = 1;
+    int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
+};
+struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; };   // vec: fp32 [B,C]
+struct ConvPart { std::string name; int cout; };
+struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; };
+
+}  // namespace
+
+struct sr_model {
+    sr_ctx* ctx = nullptr;
+    int kind = 0;
+    sr_model_cfg cfg{};
+    int T = SR_DTYPE_BF16;
+    std::vector<Param> params;
+    std::vector<ConvSpec> convs;
+    std::vector<BufSpec> bufs;
+    std::vector<void*> bufp;
+    std::vector<float*> dense_dev;    // per param index (dense kernels / biases on device), else nullptr
+    std::vector<Op> ops;
+    int in_C = 3, out_C = 3, out_mul = 1; bool out_vec = false;
+    bool finalized = false;
+    int aB = 0, aH = 0, aW = 0;       // dims the workspaces are currently sized for
+
+    int find_param(const std::string& n, int which) const {
+        for (size_t i = 0; i < params.size(); ++i) if (params[i].which == which && params[i].name == n) return (int)i;
+        return -1;
+    }
+    void free_bufs() { for (auto& p : bufp) { if (p) ctx->dfree(p); p = nullptr; } aB = aH = aW = 0; }
+};
+
+namespace {
+
+struct Builder {
+    sr_model* m;
+    int esz() const { return dtype_size(m->T); }
+    int E() const { return 16 / esz(); }
+    int buf(int C, int mul = 1, int shift = 0) {
+        BufSpec b; b.C = C; b.mul = mul; b.shift = shift; b.Cbuf = round_up(C, 32);
+        m->bufs.push_back(b); return (int)m->bufs.size() - 1;
+    }
+    int vecbuf(int C) { BufSpec b; b.C = C; b.vec = true; b.Cbuf = C; m->bufs.push_back(b); return (int)m->bufs.size() - 1; }
+    void add_layer_params(const std::string& name, std::vector<int64_t> kshape) {
+        Param k; k.name = name; k.which = SR_WEIGHT_KERNEL; k.shape = kshape; m->params.push_back(k);
+        Param b; b.name = name; b.which = SR_WEIGHT_BIAS; b.shape = {kshape.back()}; m->params.push_back(b);
+    }
+    int conv_spec(std::vector<ConvPart> parts, int KS, int Cin) {
+        ConvSpec c; c.parts = parts; c.KS = KS; c.Cin = Cin; c.Cout = 0;
+        for (auto& p : parts) { c.Cout += p.cout; add_layer_params(p.name, {KS, KS, Cin, p.cout}); }
+        m->convs.push_back(c); return (int)m->convs.size() - 1;
+    }
+    Op& conv(const std::string& name, int KS, int Cin, int Cout, Ref in, Ref out, int act = SR_ACT_LINEAR) {
+        Op o; o.kind = OP_CONV; o.conv = conv_spec({{name, Cout}}, KS, Cin); o.in = in; o.out = out; o.act = act;
+        m->ops.push_back(o); return m->ops.back();
+    }
+    // the same Keras layer executed a second time into another buffer (no new parameters)
+    Op& conv_again(int spec, Ref in, Ref out, int act = SR_ACT_LINEAR) {
+        Op o; o.kind = OP_CONV; o.conv = spec; o.in = in; o.out = out; o.act = act;
+        m->ops.push_back(o); return m->ops.back();
+    }
+    // SelfAttention(64) on `x` (64 ch) -> `y` (64 ch); qkv: 64-ch scratch, ao: 32-ch scratch (same resolution)
+    void self_attention(const std::string& name, int x, int y, int qkv, int ao) {
+        Op p; p.kind = OP_CONV; p.conv = conv_spec({{name + "_f", 8}, {name + "_g", 8}, {name + "_h", 32}}, 1, 64);
+        p.in = {x, 0}; p.out = {qkv, 0}; m->ops.push_back(p);
+        Op a; a.kind = OP_ATTN; a.in = {qkv, 0}; a.out = {ao, 0}; m->ops.push_back(a);
+        Op& v = conv(name + "_v", 1, 32, 64, {ao, 0}, {y, 0});
+        v.skip1 = {x, 0}; v.beta1 = 1.f;
+    }
+};
+
+int build_srcnn(sr_model* m) {
+    Builder b{m};
+    const int C = m->cfg.channels;
+    m->in_C = C; m->out_C = C; m->out_mul = 1;
+    const int x0 = b.buf(b.E()), c1 = b.buf(96), c2 = b.buf(32);
+    m->bufs[x0].Cbuf = b.E();
+    Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
+    b.conv("conv2d", 9, C, 96, {x0, 0}, {c1, 0}, SR_ACT_RELU);
+    b.conv("conv2d_1", 1, 96, 32, {c1, 0}, {c2, 0}, SR_ACT_RELU);
+    b.conv("conv2d_2", 5, 32, C, {c2, 0}, {-2, 0});
+    return SR_OK;
+}
+
+int build_edsr(sr_model* m) {
+    Builder b{m};
+    const sr_model_cfg& c = m->cfg;
+    const int C = c.channels, F = c.num_filters, s = c.scale_factor;
+    if (s != 2 && s != 3 && s != 4) return m->ctx->fail(SR_ERR_INVALID, "Scale factor " + std::to_string(s) + " not supported. Use 2, 3, or 4.");
+    m->in_C = C; m->out_C = C; m->out_mul = s;
+    int li = 0;
+    auto lname = [&]() { std::string n = li == 0 ? "conv2d" : "conv2d_" + std::to_string(li); ++li; return n; };
+    const int x0 = b.buf(b.E());
+    m->bufs[x0].Cbuf = b.E();
+    const int head = b.buf(F), tmp = b.buf(F), ra = b.buf(F), rb = b.buf(F);
+    Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
+    b.conv(lname(), 3, C, F, {x0, 0}, {head, 0});
+    int cur = head;
+    for (int i = 0; i < c.num_blocks; ++i) {
+        const int nxt = (cur == ra) ? rb : ra;
+        b.conv(lname(), 3, F, F, {cur, 0}, {tmp, 0}, SR_ACT_RELU);
+        Op& o = b.conv(lname(), 3, F, F, {tmp, 0}, {nxt, 0});
+        o.alpha = c.res_scaling; o.skip1 = {cur, 0}; o.beta1 = 1.f;      // x + res_scaling*conv (EDSR_model.py:68-72)
+        cur = nxt;
+    }
+    const int body = (cur == ra) ? rb : ra;
+    { Op& o = b.conv(lname(), 3, F, F, {cur, 0}, {body, 0}); o.skip1 = {head, 0}; o.beta1 = 1.f; }
+    int up = body, mul = 1;
+    const int nup = s == 4 ? 2 : 1, r = s == 4 ? 2 : s;
+    for (int i = 0; i < nup; ++i) {
+        mul *= r;
+        const int ub = b.buf(F, mul);
+        Op& o = b.conv(lname(), 3, F, F * r * r, {up, 0}, {ub, 0}); o.d2s = r;
+        up = ub;
+    }
+    { Op& o = b.conv(lname(), 3, F, C, {up, 0}, {-2, 0}); o.clip = 1; }
+    return SR_OK;
+}
+
+int build_esrgan(sr_model* m) {
+    Builder b{m};
+    const sr_model_cfg& c = m->cfg;
+    const int C = c.channels, G = c.growth_channels, s = c.scale_factor;
+    if (s < 1 || (s & (s - 1)) != 0) return m->ctx->fail(SR_ERR_INVALID, "ESRGAN scale_factor must be a power of two");
+    if (G <= 0 || c.num_blocks < 0) return m->ctx->fail(SR_ERR_INVALID, "ESRGAN growth_channels/num_rrdb_blocks invalid");
+    m->in_C = C; m->out_C = C; m->out_mul = s;
+    const int CC = 64 + 4 * G;
+    const int x0 = b.buf(b.E());
+    m->bufs[x0].Cbuf = b.E();
+    const int trunk = b.buf(64);
+    int cat[3] = {b.buf(CC), b.buf(CC), b.buf(CC)};
+    Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
+    b.conv("initial_conv", 3, C, 64, {x0, 0}, {trunk, 0});
+    b.conv_again((int)m->convs.size() - 1, {x0, 0}, {cat[0], 0});   // same layer again, straight into the first concat buffer
+    int X = 0, Y = 1, Z = 2;                                          // cat[X] holds the RRDB input in channels [0,64)
+    for (int r = 0; r < c.num_blocks; ++r) {
+        const int src[3] = {X, Y, Z}, dst[3] = {Y, Z, Y};
+        for (int d = 0; d < 3; ++d) {
+            const std::string dn = "rrdb_" + std::to_string(r) + "_dense" + std::to_string(d + 1);
+            const int I = cat[src[d]], O = cat[dst[d]];
+            for (int k = 1; k <= 4; ++k)
+                b.conv(dn + "_conv" + std::to_string(k), 3, 64 + (k - 1) * G, G, {I, 0}, {I, 64 + (k - 1) * G}, SR_ACT_RELU);
+            Op& o = b.conv(dn + "_conv5", 3, CC, 64, {I, 0}, {O, 0});
+            if (d < 2) { o.alpha = 0.2f; o.skip1 = {I, 0}; o.beta1 = 1.f; }                 // x + 0.2*conv5 (ESRGAN_model.py:249-252)
+            else { o.alpha = 0.04f; o.skip1 = {cat[X], 0}; o.beta1 = 1.f; o.skip2 = {I, 0}; o.beta2 = 0.2f; }
+            // d == 2: rrdb_in + 0.2*(x + 0.2*conv5)  (ESRGAN_model.py:277-280)
+        }
+        const int nX = Y, nY = Z, nZ = X; X = nX; Y = nY; Z = nZ;
+    }
+    const int t2 = b.buf(64);
+    { Op& o = b.conv("trunk_conv", 3, 64, 64, {cat[X], 0}, {t2, 0}); o.skip1 = {trunk, 0}; o.beta1 = 1.f; }
+    int cur = t2;
+    if (c.use_attention) {
+        const int qkv = b.buf(64), ao = b.buf(32), t3 = b.buf(64);
+        b.self_attention("self_attention_trunk", cur, t3, qkv, ao);
+        cur = t3;
+    }
+    int mul = 1, nup = 0;
+    for (int t = s; t > 1; t >>= 1) ++nup;
+    for (int i = 0; i < nup; ++i) {
+        mul *= 2;
+        const int u = b.buf(64, mul);
+        Op& o = b.conv("upsample_" + std::to_string(i) + "_conv", 3, 64, 256, {cur, 0}, {u, 0}, SR_ACT_LRELU);
+        o.d2s = 2;   // LeakyReLU is elementwise: applying it before the shuffle is the same function
+        cur = u;
+        if (i == 0 && c.use_attention) {
+            const int qkv = b.buf(64, mul), ao = b.buf(32, mul), ua = b.buf(64, mul);
+            b.self_attention("self_attention_upsample_0", cur, ua, qkv, ao);
+            cur = ua;
+        }
+    }
+    const int f1 = b.buf(64, mul);
+    b.conv("final_conv1", 3, 64, 64, {cur, 0}, {f1, 0}, SR_ACT_RELU);
+    b.conv("final_conv2", 3, 64, C, {f1, 0}, {-2, 0}, SR_ACT_TANH);
+    return SR_OK;
+}
+
+int build_vgg16(sr_model* m) {
+    Builder b{m};
+    const int nc = m->cfg.num_classes;
+    if (nc <= 0) return m->ctx->fail(SR_ERR_INVALID, "num_classes must be positive");
+    m->in_C = 3; m->out_C = nc; m->out_vec = true;
+    static const int cfg[5][2] = {{2, 64}, {2, 128}, {3, 256}, {3, 512}, {3, 512}};
+    const int x0 = b.buf(b.E());
+    m->bufs[x0].Cbuf = b.E();
+    Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
+    int cur = x0, cin = 3;
+    for (int blk = 0; blk < 5; ++blk) {
+        for (int k = 0; k < cfg[blk][0]; ++k) {
+            const int o = b.buf(cfg[blk][1], 1, blk);
+            b.conv("block" + std::to_string(blk + 1) + "_conv" + std::to_string(k + 1), 3, cin, cfg[blk][1], {cur, 0}, {o, 0}, SR_ACT_RELU);
+            cur = o; cin = cfg[blk][1];
+        }
+        const int pb = b.buf(cin, 1, blk + 1);
+        Op p; p.kind = OP_POOL; p.in = {cur, 0}; p.out = {pb, 0}; m->ops.push_back(p);
+        cur = pb;
+    }
+    const int g = b.vecbuf(512), d1 = b.vecbuf(256);
+    { Op o; o.kind = OP_GAP; o.in = {cur, 0}; o.out = {g, 0}; m->ops.push_back(o); }
+    b.add_layer_params("dense", {512, 256});
+    { Op o; o.kind = OP_DENSE; o.in = {g, 0}; o.out = {d1, 0}; o.In = 512; o.Out = 256; o.act = SR_ACT_RELU;
+      o.dw = m->find_param("dense", SR_WEIGHT_KERNEL); o.db = m->find_param("dense", SR_WEIGHT_BIAS); m->ops.push_back(o); }
+    b.add_layer_params("predictions", {256, nc});
+    { Op o; o.kind = OP_DENSE; o.in = {d1, 0}; o.out = {-2, 0}; o.In = 256; o.Out = nc; o.act = 100;
+      o.dw = m->find_param("predictions", SR_WEIGHT_KERNEL); o.db = m->find_param("predictions", SR_WEIGHT_BIAS); m->ops.push_back(o); }
+    return SR_OK;
+}
+
+inline void buf_hw(const BufSpec& b, int H, int W, int* h, int* w) { *h = (H * b.mul) >> b.shift; *w = (W * b.mul) >> b.shift; }
+
+int ensure_workspace(sr_model* m, int B, int H, int W) {
+    if (m->aB == B && m->aH == H && m->aW == W) return SR_OK;
+    m->free_bufs();
+    m->bufp.assign(m->bufs.size(), nullptr);
+    for (size_t i = 0; i < m->bufs.size(); ++i) {
+        const BufSpec& b = m->bufs[i];
+        size_t bytes;
+        if (b.vec) bytes = (size_t)B * b.C * sizeof(float);
+        else { int h, w; buf_hw(b, H, W, &h, &w); bytes = (size_t)B * h * w * b.Cbuf * dtype_size(m->T) + 4096; }
+        m->bufp[i] = m->ctx->dalloc(bytes);
+        if (!m->bufp[i]) { m->free_bufs(); return SR_ERR_OOM; }
+        // pad channels must read as zero: they meet zero weights, but 0*NaN would still poison a sum
+        SR_HIP(m->ctx, hipMemset(m->bufp[i], 0, bytes));
+    }
+    m->aB = B; m->aH = H; m->aW = W;
+    return SR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int sr_init(int device_id, sr_ctx** out) {
+    if (!out) return SR_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return SR_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return SR_ERR_HIP;
+    sr_ctx* c = new sr_ctx();
+    c->device = device_id;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return SR_ERR_HIP; }
+    *out = c;
+    return SR_OK;
+}
+
+void sr_destroy(sr_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipDeviceSynchronize();
+    std::vector<void*> ps;
+    for (auto& kv : ctx->allocs) ps.push_back(kv.first);
+    for (void* p : ps) ctx->dfree(p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char* sr_last_error(sr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int sr_mem_info(sr_ctx* ctx, int64_t* current_bytes, int64_t* peak_bytes) {
+    if (!ctx) return SR_ERR_INVALID;
+    if (current_bytes) *current_bytes = ctx->cur_bytes;
+    if (peak_bytes) *peak_bytes = ctx->peak_bytes;
+    return SR_OK;
+}
+
+int sr_last_forward_ms(sr_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return SR_ERR_INVALID;
+    if (!ctx->timed) return ctx->fail(SR_ERR_STATE, "no forward has run on this ctx");
+    SR_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    SR_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return SR_OK;
+}
+
+int sr_model_create(sr_ctx* ctx, int kind, const sr_model_cfg* cfg, sr_model** out) {
+    if (!ctx || !cfg || !out) return SR_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->compute_dtype != SR_DTYPE_F32 && cfg->compute_dtype != SR_DTYPE_BF16)
+        return ctx->fail(SR_ERR_INVALID, "compute_dtype must be SR_DTYPE_F32 or SR_DTYPE_BF16");
+    std::unique_ptr<sr_model> m(new sr_model());
+    m->ctx = ctx; m->kind = kind; m->cfg = *cfg; m->T = cfg->compute_dtype;
+    if (m->cfg.channels <= 0) m->cfg.channels = 3;
+    if (m->cfg.channels > 16 / dtype_size(m->T))
+        return ctx->fail(SR_ERR_INVALID, "channels must fit one 16-byte slice (<= 4 for f32, <= 8 for bf16)");
+    int rc;
+    switch (kind) {
+        case SR_MODEL_SRCNN: rc = build_srcnn(m.get()); break;
+        case SR_MODEL_EDSR: rc = build_edsr(m.get()); break;
+        case SR_MODEL_ESRGAN_G: rc = build_esrgan(m.get()); break;
+        case SR_MODEL_VGG16: rc = build_vgg16(m.get()); break;
+        default: return ctx->fail(SR_ERR_INVALID, "unknown model kind");
+    }
+    if (rc) return rc;
+    m->dense_dev.assign(m->params.size(), nullptr);
+    *out = m.release();
+    return SR_OK;
+}
+
+void sr_model_destroy(sr_model* m) {
+    if (!m) return;
+    (void)hipDeviceSynchronize();
+    m->free_bufs();
+    for (auto& c : m->convs) conv_free_weights(m->ctx, &c.w);
+    for (auto& p : m->dense_dev) if (p) m->ctx->dfree(p);
+    delete m;
+}
+
+int sr_model_num_params(sr_model* m) { return m ? (int)m->params.size() : SR_ERR_INVALID; }
+
+int sr_model_param_info(sr_model* m, int index, const char** name, int* which, int64_t shape[4], int* ndim) {
+    if (!m || index < 0 || index >= (int)m->params.size()) return SR_ERR_INVALID;
+    const Param& p = m->params[index];
+    if (name) *name = p.name.c_str();
+    if (which) *which = p.which;
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape) for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return SR_OK;
+}
+
+int sr_model_set_weight(sr_model* m, const char* name, int which, const float* host, const int64_t* shape, int ndim) {
+    if (!m || !name || !host || !shape) return SR_ERR_INVALID;
+    const int i = m->find_param(name, which);
+    if (i < 0) return m->ctx->fail(SR_ERR_NAME, std::string("no parameter '") + name + "' (which=" + std::to_string(which) + ")");
+    Param& p = m->params[i];
+    bool ok = ndim == (int)p.shape.size();
+    for (int d = 0; ok && d < ndim; ++d) ok = shape[d] == p.shape[d];
+    if (!ok) return m->ctx->fail(SR_ERR_INVALID, std::string("shape mismatch for '") + name + "'");
+    p.host.assign(host, host + p.count());
+    p.set = true;
+    m->finalized = false;
+    return SR_OK;
+}
+
+int sr_model_finalize(sr_model* m) {
+    if (!m) return SR_ERR_INVALID;
+    sr_ctx* ctx = m->ctx;
+    for (auto& p : m->params)
+        if (!p.set) return ctx->fail(SR_ERR_STATE, "parameter '" + p.name + (p.which ? "' bias" : "' kernel") + " was never set");
+    for (auto& c : m->convs) {
+        conv_free_weights(ctx, &c.w);
+        const int taps = c.KS * c.KS;
+        std::vector<float> k((size_t)taps * c.Cin * c.Cout), bias(c.Cout);
+        int co0 = 0;
+        for (auto& part : c.parts) {
+            const Param& pk = m->params[m->find_param(part.name, SR_WEIGHT_KERNEL)];
+            const Param& pb = m->params[m->find_param(part.name, SR_WEIGHT_BIAS)];
+            for (int t = 0; t < taps; ++t)
+                for (int ci = 0; ci < c.Cin; ++ci)
+                    for (int co = 0; co < part.cout; ++co)
+                        k[((size_t)t * c.Cin + ci) * c.Cout + co0 + co] = pk.host[((size_t)t * c.Cin + ci) * part.cout + co];
+            for (int co = 0; co < part.cout; ++co) bias[co0 + co] = pb.host[co];
+            co0 += part.cout;
+        }
+        int rc = conv_pack_weights(ctx, k.data(), bias.data(), c.KS, c.Cin, c.Cout, m->T, &c.w);
+        if (rc) return rc;
+    }
+    for (auto& op : m->ops) {
+        if (op.kind != OP_DENSE) continue;
+        for (int pi : {op.dw, op.db}) {
+            if (m->dense_dev[pi]) ctx->dfree(m->dense_dev[pi]);
+            const Param& p = m->params[pi];
+            m->dense_dev[pi] = static_cast<float*>(ctx->dalloc(sizeof(float) * p.count()));
+            if (!m->dense_dev[pi]) return SR_ERR_OOM;
+            SR_HIP(ctx, hipMemcpy(m->dense_dev[pi], p.host.data(), sizeof(float) * p.count(), hipMemcpyHostToDevice));
+        }
+    }
+    m->finalized = true;
+    return SR_OK;
+}
+
+int sr_model_output_shape(sr_model* m, int B, int H, int W, int C, int64_t out_shape[4]) {
+    if (!m || !out_shape) return SR_ERR_INVALID;
+    (void)C;
+    if (m->out_vec) { out_shape[0] = B; out_shape[1] = m->out_C; out_shape[2] = 1; out_shape[3] = 1; }
+    else { out_shape[0] = B; out_shape[1] = (int64_t)H * m->out_mul; out_shape[2] = (int64_t)W * m->out_mul; out_shape[3] = m->out_C; }
+    return SR_OK;
+}
+
+int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, int C, void* y, int64_t y_capacity, void* stream) {
+    if (!m) return SR_ERR_INVALID;
+    sr_ctx* ctx = m->ctx;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!m->finalized) return ctx->fail(SR_ERR_STATE, "sr_model_finalize has not been called");
+    if (!x || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    if (io_dtype != SR_DTYPE_F32 && io_dtype != SR_DTYPE_BF16) return ctx->fail(SR_ERR_INVALID, "io dtype must be f32 or bf16");
+    if (io_dtype == SR_DTYPE_BF16 && m->T == SR_DTYPE_F32) return ctx->fail(SR_ERR_INVALID, "an fp32 model takes fp32 tensors");
+    if (C != m->in_C) return ctx->fail(SR_ERR_INVALID, "channel count does not match the model");
+    if (B == 0) return SR_OK;   // keras predict on an empty batch returns an empty array
+    if (B < 0 || H <= 0 || W <= 0) return ctx->fail(SR_ERR_INVALID, "bad tensor shape");
+    int64_t os[4];
+    sr_model_output_shape(m, B, H, W, C, os);
+    if (y_capacity < os[0] * os[1] * os[2] * os[3]) return ctx->fail(SR_ERR_CAPACITY, "output buffer too small");
+    if (m->kind == SR_MODEL_VGG16 && (H < 32 || W < 32)) return ctx->fail(SR_ERR_INVALID, "VGG16 needs H,W >= 32");
+    int rc = ensure_workspace(m, B, H, W);
+    if (rc) return rc;
+    SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
+    const int T = m->T;
+    for (const Op& op : m->ops) {
+        int h = H, w = W;
+        if (op.in.buf >= 0) buf_hw(m->bufs[op.in.buf], H, W, &h, &w);
+        switch (op.kind) {
+            case OP_CONVERT:
+                rc = convert_pad_launch(ctx, x, io_dtype, (int64_t)B * H * W, C, m->bufp[op.out.buf], T, m->bufs[op.out.buf].Cbuf, 1.f, 0.f, st);
+                break;
+            case OP_CONV: {
+                const ConvSpec& cs = m->convs[op.conv];
+                TensorView xin{m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff};
+                ConvEpilogue ep;
+                ep.act = op.act; ep.alpha = op.alpha; ep.clip01 = op.clip; ep.d2s_r = op.d2s;
+                if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff}; ep.beta1 = op.beta1; }
+                if (op.skip2.buf >= 0) { ep.skip2 = {m->bufp[op.skip2.buf], m->bufs[op.skip2.buf].Cbuf, op.skip2.coff}; ep.beta2 = op.beta2; }
+                if (op.out.buf == -2) {
+                    ep.out_f32 = io_dtype == SR_DTYPE_F32;
+                    rc = conv_launch(ctx, cs.w, xin, B, h, w, y, m->out_C, 0, ep, st);
+                } else {
+                    rc = conv_launch(ctx, cs.w, xin, B, h, w, m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, ep, st);
+                }
+                break;
+            }
+            case OP_ATTN:
+                rc = attention_launch(ctx, T, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, /*q=g*/ 8, /*k=f*/ 0, /*v=h*/ 16, B, h * w,
+                                      m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, 0, st);
+                break;
+            case OP_POOL:
+                rc = maxpool2_launch(ctx, T, m->bufp[op.in.buf], B, h, w, m->bufs[op.in.buf].C, m->bufs[op.in.buf].Cbuf, m->bufp[op.out.buf],
+                                     m->bufs[op.out.buf].Cbuf, st);
+                break;
+            case OP_GAP:
+                rc = gap_launch(ctx, T, m->bufp[op.in.buf], B, h * w, m->bufs[op.in.buf].C, m->bufs[op.in.buf].Cbuf,
+                                static_cast<float*>(m->bufp[op.out.buf]), st);
+                break;
+            case OP_DENSE: {
+                const float* xin = static_cast<const float*>(m->bufp[op.in.buf]);
+                if (op.out.buf == -2) {
+                    if (io_dtype == SR_DTYPE_F32) rc = dense_launch(ctx, xin, m->dense_dev[op.dw], m->dense_dev[op.db], B, op.In, op.Out, op.act, static_cast<float*>(y), 0, nullptr, st);
+                    else rc = dense_launch(ctx, xin, m->dense_dev[op.dw], m->dense_dev[op.db], B, op.In, op.Out, op.act, nullptr, io_dtype, y, st);
+                } else {
+                    rc = dense_launch(ctx, xin, m->dense_dev[op.dw], m->dense_dev[op.db], B, op.In, op.Out, op.act, static_cast<float*>(m->bufp[op.out.buf]), 0, nullptr, st);
+                }
+                break;
+            }
+        }
+        if (rc) return rc;
+    }
+    SR_HIP(ctx, hipEventRecord(ctx->ev1, st));
+    ctx->timed = true;
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- single ops
+int sr_conv2d(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int Cin, const float* w_hwio, const float* bias, int KH, int KW,
+              int Cout, int act, float alpha, const void* skip1, float beta1, const void* skip2, float beta2, int clip01, int d2s_r,
+              void* y, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!x || !w_hwio || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    if (KH != KW) return ctx->fail(SR_ERR_INVALID, "square kernels only");
+    if (dtype != SR_DTYPE_F32 && dtype != SR_DTYPE_BF16) return ctx->fail(SR_ERR_INVALID, "dtype must be f32 or bf16");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ctx->fail(SR_ERR_INVALID, "bad tensor shape");
+    ConvWeights cw;
+    int rc = conv_pack_weights(ctx, w_hwio, bias, KH, Cin, Cout, dtype, &cw);
+    if (rc) return rc;
+    const int esz = dtype_size(dtype);
+    const int Cp = cw.thin ? cw.CinP : round_up(cw.CinP, 32);
+    void* xp = ctx->dalloc((size_t)B * H * W * Cp * esz + 4096);
+    if (!xp) { conv_free_weights(ctx, &cw); return SR_ERR_OOM; }
+    rc = convert_pad_launch(ctx, x, dtype, (int64_t)B * H * W, Cin, xp, dtype, Cp, 1.f, 0.f, st);
+    if (!rc) {
+        ConvEpilogue ep;
+        ep.act = act; ep.alpha = alpha; ep.clip01 = clip01; ep.d2s_r = d2s_r < 1 ? 1 : d2s_r;
+        if (skip1) { ep.skip1 = {skip1, Cout, 0}; ep.beta1 = beta1; }
+        if (skip2) { ep.skip2 = {skip2, Cout, 0}; ep.beta2 = beta2; }
+        const int r = ep.d2s_r;
+        rc = conv_launch(ctx, cw, TensorView{xp, Cp, 0}, B, H, W, y, Cout / (r * r), 0, ep, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    ctx->dfree(xp);
+    conv_free_weights(ctx, &cw);
+    if (!rc && e != hipSuccess) return ctx->fail(SR_ERR_HIP, std::string("conv2d: ") + hipGetErrorString(e));
+    return rc;
+}
+
+int sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, const float* wf, const float* bf, const float* wg,
+                      const float* bg, const float* wh, const float* bh, const float* wv, const float* bv, void* y, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C != 64) return ctx->fail(SR_ERR_INVALID, "SelfAttention kernel is built for channels=64 (d_qk=8, d_v=32)");
+    if (dtype != SR_DTYPE_F32 && dtype != SR_DTYPE_BF16) return ctx->fail(SR_ERR_INVALID, "dtype must be f32 or bf16");
+    if (B <= 0 || H <= 0 || W <= 0) return ctx->fail(SR_ERR_INVALID, "bad tensor shape");
+    // f | g | h side by side: one 1x1 conv 64 -> 48
+    std::vector<float> wp((size_t)64 * 48), bp(48);
+    for (int ci = 0; ci < 64; ++ci) {
+        for (int co = 0; co < 8; ++co) { wp[(size_t)ci * 48 + co] = wf[ci * 8 + co]; wp[(size_t)ci * 48 + 8 + co] = wg[ci * 8 + co]; }
+        for (int co = 0; co < 32; ++co) wp[(size_t)ci * 48 + 16 + co] = wh[ci * 32 + co];
+    }
+    for (int co = 0; co < 8; ++co) { bp[co] = bf ? bf[co] : 0.f; bp[8 + co] = bg ? bg[co] : 0.f; }
+    for (int co = 0; co < 32; ++co) bp[16 + co] = bh ? bh[co] : 0.f;
+    ConvWeights cp, cv;
+    int rc = conv_pack_weights(ctx, wp.data(), bp.data(), 1, 64, 48, dtype, &cp);
+    if (rc) return rc;
+    rc = conv_pack_weights(ctx, wv, bv, 1, 32, 64, dtype, &cv);
+    if (rc) { conv_free_weights(ctx, &cp); return rc; }
+    const int esz = dtype_size(dtype);
+    const int64_t npix = (int64_t)B * H * W;
+    void* qkv = ctx->dalloc((size_t)npix * 64 * esz + 4096);
+    void* ao = ctx->dalloc((size_t)npix * 32 * esz + 4096);
+    if (!qkv || !ao) rc = SR_ERR_OOM;
+    if (!rc) rc = (hipMemsetAsync(qkv, 0, (size_t)npix * 64 * esz, st) == hipSuccess) ? SR_OK : ctx->fail(SR_ERR_HIP, "memset");
+    ConvEpilogue e0;
+    if (!rc) rc = conv_launch(ctx, cp, TensorView{x, 64, 0}, B, H, W, qkv, 64, 0, e0, st);
+    if (!rc) rc = attention_launch(ctx, dtype, qkv, 64, 8, 0, 16, B, H * W, ao, 32, 0, st);
+    ConvEpilogue e1;
+    e1.skip1 = {x, 64, 0}; e1.beta1 = 1.f;
+    if (!rc) rc = conv_launch(ctx, cv, TensorView{ao, 32, 0}, B, H, W, y, 64, 0, e1, st);
+    hipError_t e = hipStreamSynchronize(st);
+    ctx->dfree(qkv); ctx->dfree(ao);
+    conv_free_weights(ctx, &cp); conv_free_weights(ctx, &cv);
+    if (!rc && e != hipSuccess) return ctx->fail(SR_ERR_HIP, std::string("self_attention: ") + hipGetErrorString(e));
+    return rc;
+}
+
+int sr_bicubic(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, void* y, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    if (!x || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return bicubic_launch(ctx, x, dtype, B, H, W, C, outH, outW, y, dtype, C, static_cast<hipStream_t>(stream));
+}
+
+int sr_psnr(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float max_val, float* out_B, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !b || !out_B) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return psnr_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), B, (int64_t)H * W * C, max_val, out_B,
+                       static_cast<hipStream_t>(stream));
+}
+
+int sr_ssim(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float max_val, float* out_B, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !b || !out_B) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return ssim_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), B, H, W, C, max_val, out_B,
+                       static_cast<hipStream_t>(stream));
+}
+
+int sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !b || !out1) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return mse_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), n, out1, static_cast<hipStream_t>(stream));
+}
+
+int sr_extract_patches(sr_ctx* ctx, const float* img, int H, int W, int C, int patch, int stride, float mul, float add, int out_dtype,
+                       void* out, int64_t out_capacity, int* n_patches, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    if (H <= 0 || W <= 0 || C <= 0 || patch <= 0 || stride <= 0) return ctx->fail(SR_ERR_INVALID, "bad shape/patch/stride");
+    const int ph = pad_amount(H, patch, stride), pw = pad_amount(W, patch, stride);
+    if (ph >= H || pw >= W) return ctx->fail(SR_ERR_INVALID, "reflect padding needs pad < image size");   // np.pad would wrap repeatedly
+    const int Hp = H + ph, Wp = W + pw;
+    const int ny = Hp >= patch ? (Hp - patch) / stride + 1 : 0, nx = Wp >= patch ? (Wp - patch) / stride + 1 : 0;
+    if (n_patches) *n_patches = ny * nx;
+    if (!out) return SR_OK;
+    if (!img) return ctx->fail(SR_ERR_INVALID, "null image");
+    if (out_dtype != SR_DTYPE_F32 && out_dtype != SR_DTYPE_BF16) return ctx->fail(SR_ERR_INVALID, "out dtype must be f32 or bf16");
+    if (out_capacity < (int64_t)ny * nx * patch * patch * C) return ctx->fail(SR_ERR_CAPACITY, "patch buffer too small");
+    return extract_patches_launch(ctx, img, H, W, C, patch, stride, mul, add, out_dtype, out, ny, nx, static_cast<hipStream_t>(stream));
+}
+
+int sr_overlap_add(sr_ctx* ctx, const void* patches, int in_dtype, int H, int W, int C, int patch, int stride, int scale, float mul,
+                   float add, float* out, void* stream) {
+    if (!ctx) return SR_ERR_INVALID;
+    if (!patches || !out) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    if (H <= 0 || W <= 0 || C <= 0 || patch <= 0 || stride <= 0 || scale <= 0) return ctx->fail(SR_ERR_INVALID, "bad shape/patch/stride");
+    if (in_dtype != SR_DTYPE_F32 && in_dtype != SR_DTYPE_BF16) return ctx->fail(SR_ERR_INVALID, "patch dtype must be f32 or bf16");
+    const int Hp = H + pad_amount(H, patch, stride), Wp = W + pad_amount(W, patch, stride);
+    const int ny = (Hp - patch) / stride + 1, nx = (Wp - patch) / stride + 1;
+    return overlap_add_launch(ctx, patches, in_dtype, H, W, C, patch, stride, scale, mul, add, ny, nx, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// attention.hip -- streaming-softmax core of the reference's SelfAttention layer
+// (ESRGAN_model.py:57-65): s = g.f^T over N = H*W tokens, beta = softmax(s, axis=-1), o = beta.h,
+// with d_qk = C/8 = 8 and d_v = C/2 = 32, no 1/sqrt(d) scale.  The N x N score matrix never
+// reaches HBM (the reference materialises it, which is why it cannot leave 48x48 patches).
+//
+// Layout.  Transposed formulation so the softmax axis (keys) lies along a lane's registers:
+//   S^T[key][query] = K.Q^T   (MFMA A = key fragment, B = query fragment)
+//   O^T[dv][query] += V^T[dv][key] . P^T[key][query]   (A = V^T fragment from LDS, B = P^T straight
+//   from the S^T accumulator registers -- no lane movement, see the accumulator-as-operand rule).
+// A lane owns one query (column) and 16 of a 32-key tile's keys; the other 16 sit in lane+32,
+// so the running max needs a single cross-half exchange per tile.
+//
+// Work split: workgroup = 4 waves = 128 queries of one image; every wave walks all keys in tiles
+// of 64; the V tile is transposed into LDS once per workgroup per tile.
+// HBM bytes per launch (algorithmic): B*N*(8+8+32+32)*sizeof(T); FLOP 2*B*N^2*(8+32);
+// exp count B*N^2 (the binding resource: d_qk/d_v are tiny).
+#include "common.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+
+template <typename T> struct AT;
+template <> struct AT<bf16_t> { static constexpr int PITCH = KV_TILE * 2 + 8; };    // bytes per V^T row in LDS
+template <> struct AT<float>  { static constexpr int PITCH = KV_TILE * 4 + 4; };
+
+struct AttnParams {
+    const char* qkv; int64_t cs; int qoff, koff, voff;
+    char* o; int64_t o_cs; int o_coff;
+    int N;
+};
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
+    constexpr int PITCH = AT<T>::PITCH;
+    constexpr bool BF = sizeof(T) == 2;
+    __shared__ __attribute__((aligned(16))) char vt[32 * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int N = p.N;
+    const T* base = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * N * p.cs;
+    const int q = blockIdx.x * 128 + wave * 32 + r;
+    const int qc = q < N ? q : N - 1;
+
+    // query fragment (B operand of S^T = K.Q^T)
+    bf16x8 qb = {};
+    float qf[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const T* qp = base + (int64_t)qc * p.cs + p.qoff;
+        if constexpr (BF) {
+            if (h == 0) qb = *reinterpret_cast<const bf16x8*>(qp);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[j] = qp[2 * j + h];
+        }
+    }
+
+    f32x16 oacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // V staging assignment: thread -> (key within tile, 8-channel octet)
+    const int skey = tid >> 2, soct = tid & 3;
+
+    for (int k0 = 0; k0 < N; k0 += KV_TILE) {
+        __syncthreads();   // previous tile's V^T reads are done
+        {
+            const int key = k0 + skey;
+            const T* vp = base + (int64_t)(key < N ? key : N - 1) * p.cs + p.voff + soct * 8;
+            if constexpr (BF) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(vp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<bf16_t*>(vt + (soct * 8 + e) * PITCH + skey * 2) = v[e];
+            } else {
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    *reinterpret_cast<float*>(vt + (soct * 8 + e) * PITCH + skey * 4) = v0[e];
+                    *reinterpret_cast<float*>(vt + (soct * 8 + 4 + e) * PITCH + skey * 4) = v1[e];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < KV_TILE / 32; ++sub) {
+            const int kb = k0 + sub * 32;
+            if (kb >= N) break;
+            // ---- S^T = K . Q^T
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            {
+                const int key = kb + r;
+                const T* kp = base + (int64_t)(key < N ? key : N - 1) * p.cs + p.koff;
+                if constexpr (BF) {
+                    bf16x8 kf = {};
+                    if (h == 0) kf = *reinterpret_cast<const bf16x8*>(kp);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb, s, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * j + h], qf[j], s, 0, 0, 0);
+                }
+            }
+            // ---- online softmax over this tile's 32 keys (16 here, 16 in lane^32)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key >= N) s[i] = -INFINITY;
+                mx = fmaxf(mx, s[i]);
+            }
+            mx = fmaxf(mx, xhalf(mx));
+            const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 live key
+            const float alpha = __expf(m_run - m_new);     // exp(-inf) = 0 on the first tile
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = __expf(s[i] - m_new); psum += s[i]; }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
+            // ---- O^T += V^T . P^T
+            if constexpr (BF) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[8 * ks + j];
+                    const char* vrow = vt + r * PITCH + (sub * 32 + 16 * ks + 4 * h) * 2;
+                    bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow);
+                    bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + 16);
+                    bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int krow = sub * 32 + (i & 3) + 8 * (i >> 2);
+                    const float va = *reinterpret_cast<const float*>(vt + r * PITCH + (krow + 4 * h) * 4);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s[i], oacc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float l_tot = l_run + xhalf(l_run);
+    const float inv = 1.f / l_tot;
+    if (q < N) {
+        T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * N + q) * p.o_cs + p.o_coff;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 8 * g + 4 * h;
+            if constexpr (BF) {
+                bf16x4 t = {(bf16_t)(oacc[4 * g] * inv), (bf16_t)(oacc[4 * g + 1] * inv), (bf16_t)(oacc[4 * g + 2] * inv),
+                            (bf16_t)(oacc[4 * g + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(op + d0) = t;
+            } else {
+                f32x4 t = {oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + d0) = t;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qoff, int koff, int voff, int B, int N,
+                     void* o, int64_t o_cs, int o_coff, hipStream_t st) {
+    if (B <= 0 || N <= 0) return ctx->fail(SR_ERR_INVALID, "attention: empty tensor");
+    const int esz = dtype_size(dtype);
+    if ((cs * esz) % 16 || (qoff * esz) % 16 || (koff * esz) % 16 || (voff * esz) % 16 || (o_cs * esz) % 16 || (o_coff * esz) % 16)
+        return ctx->fail(SR_ERR_INVALID, "attention: views must be 16-byte aligned");
+    AttnParams p{static_cast<const char*>(qkv), cs, qoff, koff, voff, static_cast<char*>(o), o_cs, o_coff, N};
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)B);
+    if (dtype == SR_DTYPE_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(256), 0, st, p);
+    else if (dtype == SR_DTYPE_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, st, p);
+    else return ctx->fail(SR_ERR_INVALID, "attention: dtype must be f32 or bf16");
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}

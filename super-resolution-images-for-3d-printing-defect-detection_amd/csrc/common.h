@@ -1,0 +1,124 @@
+// common.h -- internal declarations shared by the libsr355 translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sr355.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// context: one per GPU.  Owns nothing but its tracked allocations and two timing events.
+// ---------------------------------------------------------------------------------------------
+struct sr_ctx {
+    int device = 0;
+    std::string err;
+    int64_t cur_bytes = 0, peak_bytes = 0;
+    std::unordered_map<void*, size_t> allocs;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+
+    void* scratch_buf = nullptr;
+    size_t scratch_cap = 0;
+
+    void* dalloc(size_t bytes);   // nullptr on failure (err set)
+    void dfree(void* p);
+    void* scratch(size_t bytes);  // reduction scratch; stream-ordered reuse (one stream per ctx at a time)
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+};
+
+#define SR_HIP(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return (ctx)->fail(SR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+static inline int dtype_size(int dt) { return dt == SR_DTYPE_F32 ? 4 : (dt == SR_DTYPE_BF16 ? 2 : 1); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------
+// conv: packed weights + launch
+// ---------------------------------------------------------------------------------------------
+struct ConvWeights {          // device-resident, MFMA-fragment-ordered (see conv.hip header)
+    void* w = nullptr;        // packed kernel
+    float* bias = nullptr;    // [CoutP] fp32, zero padded
+    int dtype = SR_DTYPE_BF16;
+    int KS = 3, Cin = 0, Cout = 0;
+    int CinP = 0, CoutP = 0;  // padded sizes the kernel iterates over
+    int thin = 0;             // 1: Cin fits one 16-byte slice per pixel (taps paired in a k-group)
+    int KGPT = 2;             // wide: k-groups per tap per stage (2 -> 64 B of channels, 4 -> 128 B)
+    int NT = 1;               // 32-wide cout blocks per workgroup
+    int nchunks = 1;          // wide: Cin stages;  thin: unused
+    size_t bytes = 0;
+};
+
+struct TensorView {           // NHWC view with a channel stride/offset (elements)
+    const void* p = nullptr;
+    int64_t cs = 0;           // channels per pixel in the underlying buffer
+    int coff = 0;             // first channel of this view
+};
+
+struct ConvEpilogue {
+    int act = SR_ACT_LINEAR;
+    float alpha = 1.f;
+    TensorView skip1, skip2;  // same dtype as the conv's compute dtype; p == nullptr -> unused
+    float beta1 = 0.f, beta2 = 0.f;
+    int clip01 = 0;
+    int d2s_r = 1;            // depth_to_space block (1 = none)
+    int out_f32 = 0;          // write fp32 even when computing in bf16
+};
+
+// host: pack HWIO fp32 weights (+bias) for the device.  Returns SR_OK or error (ctx->err set).
+int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS, int Cin, int Cout,
+                      int dtype, ConvWeights* out);
+void conv_free_weights(sr_ctx* ctx, ConvWeights* w);
+// x view must expose >= w.CinP channels starting at coff (extra ones multiplied by zero weights).
+int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W,
+                void* y, int64_t y_cs, int y_coff, const ConvEpilogue& ep, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// attention core: o = softmax(q k^T) v per image, tokens N=H*W.
+// qkv: [B,N,cs] with k(f) at channel koff (8 ch), q(g) at qoff (8 ch), v(h) at voff (32 ch);
+// o: [B,N,o_cs] 32 channels at o_coff.  dtype = compute dtype of both.
+// ---------------------------------------------------------------------------------------------
+int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qoff, int koff, int voff,
+                     int B, int N, void* o, int64_t o_cs, int o_coff, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// small ops (imgops.hip)
+// ---------------------------------------------------------------------------------------------
+// [B,H,W,C] of in_dtype -> [B,H,W,Cp] of out_dtype, channels >= C zero-filled, v*mul+add on real ones.
+int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype,
+                       int Cp, float mul, float add, hipStream_t st);
+int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y,
+                    int64_t y_cs, hipStream_t st);
+int gap_launch(sr_ctx* ctx, int dtype, const void* x, int B, int HW, int C, int64_t x_cs, float* y, hipStream_t st);
+// y[b,o] = act(sum_i x[b,i] w[i,o] + bias[o]); act: SR_ACT_* or 100 = softmax over o.  fp32 in/out.
+int dense_launch(sr_ctx* ctx, const float* x, const float* w, const float* bias, int B, int In, int Out, int act,
+                 float* y, int y_dtype, void* y_typed, hipStream_t st);
+int bicubic_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW,
+                   void* y, int out_dtype, int64_t y_cs, hipStream_t st);
+int psnr_launch(sr_ctx* ctx, const float* a, const float* b, int B, int64_t n_per_image, float max_val, float* out,
+                hipStream_t st);
+int ssim_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float max_val, float* out,
+                hipStream_t st);
+int mse_launch(sr_ctx* ctx, const float* a, const float* b, int64_t n, float* out, hipStream_t st);
+int extract_patches_launch(sr_ctx* ctx, const float* img, int H, int W, int C, int patch, int stride, float mul,
+                           float add, int out_dtype, void* out, int ny, int nx, hipStream_t st);
+int overlap_add_launch(sr_ctx* ctx, const void* patches, int in_dtype, int H, int W, int C, int patch, int stride,
+                       int scale, float mul, float add, int ny, int nx, float* out, hipStream_t st);
+
+static inline int pad_amount(int n, int patch, int stride) {
+    // reference: loading_methods.py:12-17
+    int pad = (n % stride != 0) ? (patch - (n % stride)) % stride : 0;
+    int extra = patch - stride;
+    return pad > extra ? pad : extra;
+}

@@ -1,0 +1,522 @@
+// conv.hip -- NHWC stride-1 SAME convolution as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces the cuDNN kernels TensorFlow picks for keras Conv2D(padding="same") on the reference's
+// hot path (SRCNN_model.py:50-52, EDSR_model.py:61-121, ESRGAN_model.py:230-341, VGG16 base).
+//
+// Formulation.  D^T[cout][pixel] += W^T[cout][k] * X^T[k][pixel] with v_mfma_f32_32x32x16_bf16
+// (bf16) or 4 x v_mfma_f32_32x32x2_f32 (fp32, exact fp32 fma chain).  The weight fragment is
+// the MFMA "A" operand and the pixel fragment the "B" operand, so every lane ends up owning one
+// output pixel and groups of 4 consecutive output channels -> 8/16-byte NHWC stores.
+//
+// Work split.  A workgroup (4 waves) owns a TH x 16 pixel tile (TH = 8*MT) of one image and
+// NT*32 output channels.  Wave w owns rows [2*MT*w, 2*MT*(w+1)); an "M-block" is 2 rows x 16
+// columns = 32 pixels = the 32 columns of one MFMA.
+//
+// LDS.  The input halo tile (TH+KS-1) x (16+KS-1) pixels of one Cin chunk is staged pixel-major
+// with CS = chunk_bytes + 16 bytes per pixel (odd number of 16-byte slots -> the 16 lanes a
+// ds_read_b128 services together land on 16 distinct slots).  A tap (ky,kx) is then a constant
+// byte offset from a lane's base address.  Weights are pre-packed on the host in exactly the
+// order the lanes read them (1 KiB per (tap, k-group, cout-block), lane-linear), so the weight
+// stage is a straight copy and its ds_read_b128 is conflict free.
+//
+// k-group = the 16 bytes lane-half 0 and the 16 bytes lane-half 1 feed to one MFMA step:
+//   wide (Cin*sizeof >= 64 B): both halves sit on the same tap, consecutive channel slices;
+//   thin (Cin fits one 16-byte slice, e.g. RGB padded to 8 bf16 / 4 fp32): half 0 takes tap 2g,
+//   half 1 tap 2g+1.
+//
+// HBM traffic per launch (algorithmic): B*H*W*(Cin + Cout)*sizeof(T) (+ skips); FLOP
+// 2*B*H*W*KS^2*Cin*Cout.  DESIGN.md prices each layer against both roofs.
+#include "common.h"
+
+#include <cstring>
+
+namespace {
+
+template <typename T> struct TT;
+template <> struct TT<bf16_t> { static constexpr int E = 8; typedef bf16x8 frag; };
+template <> struct TT<float>  { static constexpr int E = 4; typedef f32x4 frag; };
+
+__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma(f32x4 a, f32x4 b, f32x16 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+
+struct ConvParams {
+    const char* in; int64_t in_cs; int in_coff;
+    const char* w; const float* bias;
+    char* out; int64_t out_cs; int out_coff; int out_f32;
+    const char* s1; int64_t s1_cs; int s1_coff; float beta1;
+    const char* s2; int64_t s2_cs; int s2_coff; float beta2;
+    float alpha; int act; int clip; int r; int Cd;
+    int B, H, W, Cout;
+    int nchunks;        // wide: Cin chunks; thin: number of k-groups (taps pairs)
+    int tilesX, tilesY;
+    int vec;            // epilogue may use 4-element vector loads/stores
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case SR_ACT_RELU: return fmaxf(v, 0.f);
+        case SR_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+        case SR_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+template <typename T> __device__ __forceinline__ void load4(const char* base, int64_t eoff, bool vec, int n, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const char* base, int64_t eoff, bool vec, int n, float v[4]) {
+    const float* p = reinterpret_cast<const float*>(base) + eoff;
+    if (vec) { f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    else { for (int e = 0; e < 4; ++e) v[e] = e < n ? p[e] : 0.f; }
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const char* base, int64_t eoff, bool vec, int n, float v[4]) {
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(base) + eoff;
+    if (vec) { bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) v[e] = (float)t[e]; }
+    else { for (int e = 0; e < 4; ++e) v[e] = e < n ? (float)p[e] : 0.f; }
+}
+template <typename T> __device__ __forceinline__ void store4(char* base, int64_t eoff, bool vec, int n, const float v[4], bool f32);
+template <> __device__ __forceinline__ void store4<float>(char* base, int64_t eoff, bool vec, int n, const float v[4], bool) {
+    float* p = reinterpret_cast<float*>(base) + eoff;
+    if (vec) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+    else { for (int e = 0; e < n; ++e) p[e] = v[e]; }
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(char* base, int64_t eoff, bool vec, int n, const float v[4], bool f32) {
+    if (f32) { store4<float>(base, eoff, vec, n, v, true); return; }
+    bf16_t* p = reinterpret_cast<bf16_t*>(base) + eoff;
+    if (vec) { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *reinterpret_cast<bf16x4*>(p) = t; }
+    else { for (int e = 0; e < n; ++e) p[e] = (bf16_t)v[e]; }
+}
+
+// Epilogue shared by both kernels: bias, activation, alpha, two scaled skips, clip, (shuffled) store.
+template <typename T, int NT, int MT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int y0, int x0, int ct,
+                                              int wave, int r, int h) {
+    const bool vec = p.vec != 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int oy = y0 + (wave * MT + m) * 2 + (r >> 4);
+        const int ox = x0 + (r & 15);
+        if (oy >= p.H || ox >= p.W) continue;
+        const int64_t pix = ((int64_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (ct * NT + n) * 32 + 8 * q + 4 * h;
+                if (c0 >= p.Cout) continue;
+                const int nv = min(4, p.Cout - c0);
+                const bool v4 = vec && nv == 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[m][n][4 * q + e] + p.bias[c0 + e];
+                    v[e] = act_apply(t, p.act) * p.alpha;
+                }
+                if (p.s1) {
+                    float s[4];
+                    load4<T>(p.s1, pix * p.s1_cs + p.s1_coff + c0, v4, nv, s);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.beta1 * s[e];
+                }
+                if (p.s2) {
+                    float s[4];
+                    load4<T>(p.s2, pix * p.s2_cs + p.s2_coff + c0, v4, nv, s);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.beta2 * s[e];
+                }
+                if (p.clip) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+                }
+                int64_t dst;
+                if (p.r <= 1) {
+                    dst = pix * p.out_cs + p.out_coff + c0;
+                    store4<T>(p.out, dst, v4, nv, v, p.out_f32 != 0);
+                } else if (v4) {   // Cd % 4 == 0 guaranteed by host when vec
+                    const int sub = c0 / p.Cd, c = c0 - sub * p.Cd;
+                    const int i = sub / p.r, j = sub - i * p.r;
+                    dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs +
+                          p.out_coff + c;
+                    store4<T>(p.out, dst, true, 4, v, p.out_f32 != 0);
+                } else {
+                    for (int e = 0; e < nv; ++e) {   // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c
+                        const int co = c0 + e, sub = co / p.Cd, c = co - sub * p.Cd;
+                        const int i = sub / p.r, j = sub - i * p.r;
+                        dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs +
+                              p.out_coff + c;
+                        store4<T>(p.out, dst, false, 1, v + e, p.out_f32 != 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wide kernel: Cin*sizeof(T) is a multiple of KGPT*32 bytes
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KS, int KGPT, int NT, int MT>
+__global__ void __launch_bounds__(256) conv_wide_kernel(ConvParams p) {
+    typedef typename TT<T>::frag frag;
+    constexpr int E = TT<T>::E;
+    constexpr int TH = 8 * MT, TW = 16;
+    constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PADK = (KS - 1) / 2, NTAP = KS * KS;
+    constexpr int SPP = KGPT * 2;
+    constexpr int CS = KGPT * 32 + 16;
+    constexpr int NIN = PH * PW * SPP;
+    constexpr int NINT = (NIN + 255) / 256;
+    constexpr int WUNITS = NTAP * KGPT * NT * 64;
+    constexpr int LIN_BYTES = (PH * PW * CS + 15) & ~15;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lin = smem;
+    char* lw = smem + LIN_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % p.tilesX; t /= p.tilesX;
+    const int ty = t % p.tilesY;
+    const int b = t / p.tilesY;
+    const int ct = blockIdx.y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const T* inb = reinterpret_cast<const T*>(p.in) + (int64_t)b * p.H * p.W * p.in_cs + p.in_coff;
+
+    // staging descriptors: unit u -> (halo pixel, 16-byte slice)
+    int soff[NINT];   // element offset of the slice inside the image (chunk 0); -1: outside the image (zero)
+    int doff[NINT];   // LDS byte offset; -1: no unit
+#pragma unroll
+    for (int i = 0; i < NINT; ++i) {
+        const int u = tid + 256 * i;
+        const int pix = u / SPP, sl = u - pix * SPP;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = y0 + py - PADK, gx = x0 + px - PADK;
+        const bool live = u < NIN;
+        const bool inside = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        doff[i] = live ? pix * CS + sl * 16 : -1;
+        soff[i] = inside ? (int)(((int64_t)gy * p.W + gx) * p.in_cs) + sl * E : -1;
+    }
+    frag pre[NINT];
+    auto issue = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NINT; ++i) {
+            const int so = soff[i];
+            frag v = *reinterpret_cast<const frag*>(inb + (so >= 0 ? so + chunk * (SPP * E) : 0));   // always a valid address
+            frag z = {};
+            pre[i] = so >= 0 ? v : z;
+        }
+    };
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = (((wave * MT + m) * 2 + (r >> 4)) * PW + (r & 15)) * CS + h * 16;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    issue(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        __syncthreads();   // previous chunk's MFMAs have read their operands
+#pragma unroll
+        for (int i = 0; i < NINT; ++i)
+            if (doff[i] >= 0) *reinterpret_cast<frag*>(lin + doff[i]) = pre[i];
+        {
+            const char* wsrc = p.w + ((int64_t)ct * p.nchunks + chunk) * (int64_t)(WUNITS * 16);
+            for (int u = tid; u < WUNITS; u += 256)
+                *reinterpret_cast<f32x4*>(lw + u * 16) = *reinterpret_cast<const f32x4*>(wsrc + u * 16);
+        }
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) issue(chunk + 1);   // next chunk's global loads fly under the MFMAs
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int toff = ((tap / KS) * PW + (tap % KS)) * CS;
+#pragma unroll
+            for (int kg = 0; kg < KGPT; ++kg) {
+                frag wf[NT], xf[MT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    wf[n] = *reinterpret_cast<const frag*>(lw + ((tap * KGPT + kg) * NT + n) * 1024 + lane * 16);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xf[m] = *reinterpret_cast<const frag*>(lin + abase[m] + toff + kg * 32);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = mma(wf[n], xf[m], acc[m][n]);
+            }
+        }
+    }
+    conv_epilogue<T, NT, MT>(p, acc, b, y0, x0, ct, wave, r, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin kernel: one 16-byte slice per pixel holds every input channel (RGB padded to 8 bf16 / 4 fp32)
+// ------------------------------------------------------------------------------------------------
+constexpr int THIN_GPS = 16;   // k-groups per weight stage
+
+template <typename T, int KS, int NT, int MT>
+__global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
+    typedef typename TT<T>::frag frag;
+    constexpr int E = TT<T>::E;
+    constexpr int TH = 8 * MT, TW = 16;
+    constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PADK = (KS - 1) / 2, NTAP = KS * KS;
+    constexpr int KGT = (NTAP + 1) / 2;
+    constexpr int NIN = PH * PW;
+    constexpr int LIN_BYTES = NIN * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lin = smem;
+    char* lw = smem + LIN_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % p.tilesX; t /= p.tilesX;
+    const int ty = t % p.tilesY;
+    const int b = t / p.tilesY;
+    const int ct = blockIdx.y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const T* inb = reinterpret_cast<const T*>(p.in) + (int64_t)b * p.H * p.W * p.in_cs + p.in_coff;
+
+    for (int u = tid; u < NIN; u += 256) {
+        const int py = u / PW, px = u - py * PW;
+        const int gy = y0 + py - PADK, gx = x0 + px - PADK;
+        const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        frag v = *reinterpret_cast<const frag*>(inb + (inside ? ((int64_t)gy * p.W + gx) * p.in_cs : 0));
+        frag z = {};
+        *reinterpret_cast<frag*>(lin + u * 16) = inside ? v : z;
+    }
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) abase[m] = (((wave * MT + m) * 2 + (r >> 4)) * PW + (r & 15)) * 16;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    for (int g0 = 0; g0 < KGT; g0 += THIN_GPS) {
+        const int ng = min(THIN_GPS, KGT - g0);
+        __syncthreads();
+        {
+            const char* wsrc = p.w + ((int64_t)ct * KGT + g0) * (int64_t)(NT * 1024);
+            for (int u = tid; u < ng * NT * 64; u += 256)
+                *reinterpret_cast<f32x4*>(lw + u * 16) = *reinterpret_cast<const f32x4*>(wsrc + u * 16);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int gi = 0; gi < ng; ++gi) {
+            int tap = 2 * (g0 + gi) + h;
+            tap = tap < NTAP ? tap : 0;   // the odd leftover slot carries zero weights
+            const int toff = ((tap / KS) * PW + (tap % KS)) * 16;
+            frag wf[NT], xf[MT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wf[n] = *reinterpret_cast<const frag*>(lw + (gi * NT + n) * 1024 + lane * 16);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xf[m] = *reinterpret_cast<const frag*>(lin + abase[m] + toff);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = mma(wf[n], xf[m], acc[m][n]);
+        }
+    }
+    conv_epilogue<T, NT, MT>(p, acc, b, y0, x0, ct, wave, r, h);
+}
+
+constexpr int MT_DEFAULT = 3;   // 24 x 16 pixel tiles: 48/96/192-pixel patches tile exactly
+
+template <typename T, int KS, int KGPT, int NT>
+int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
+    constexpr int MT = MT_DEFAULT;
+    constexpr int PH = 8 * MT + KS - 1, PW = 16 + KS - 1, CS = KGPT * 32 + 16;
+    constexpr int lds = ((PH * PW * CS + 15) & ~15) + KS * KS * KGPT * NT * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    ConvParams p = p0;
+    p.tilesX = (p.W + 15) / 16;
+    p.tilesY = (p.H + 8 * MT - 1) / (8 * MT);
+    auto kern = conv_wide_kernel<T, KS, KGPT, NT, MT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+template <typename T, int KS, int NT>
+int launch_thin(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
+    constexpr int MT = MT_DEFAULT;
+    constexpr int PH = 8 * MT + KS - 1, PW = 16 + KS - 1;
+    constexpr int KGT = (KS * KS + 1) / 2;
+    constexpr int lds = PH * PW * 16 + (KGT < THIN_GPS ? KGT : THIN_GPS) * NT * 1024;
+    ConvParams p = p0;
+    p.tilesX = (p.W + 15) / 16;
+    p.tilesY = (p.H + 8 * MT - 1) / (8 * MT);
+    auto kern = conv_thin_kernel<T, KS, NT, MT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+template <typename T, int KS, int KGPT>
+int dispatch_wide_nt(sr_ctx* ctx, const ConvParams& p, int NT, int nct, hipStream_t st) {
+    switch (NT) {
+        case 1: return launch_wide<T, KS, KGPT, 1>(ctx, p, nct, st);
+        case 2: return launch_wide<T, KS, KGPT, 2>(ctx, p, nct, st);
+        case 3: return launch_wide<T, KS, KGPT, 3>(ctx, p, nct, st);
+    }
+    return ctx->fail(SR_ERR_INVALID, "conv: unsupported NT");
+}
+template <typename T, int KS>
+int dispatch_thin_nt(sr_ctx* ctx, const ConvParams& p, int NT, int nct, hipStream_t st) {
+    switch (NT) {
+        case 1: return launch_thin<T, KS, 1>(ctx, p, nct, st);
+        case 2: return launch_thin<T, KS, 2>(ctx, p, nct, st);
+        case 3: return launch_thin<T, KS, 3>(ctx, p, nct, st);
+    }
+    return ctx->fail(SR_ERR_INVALID, "conv: unsupported NT");
+}
+
+template <typename T>
+int dispatch(sr_ctx* ctx, const ConvWeights& w, const ConvParams& p, int nct, hipStream_t st) {
+    if (w.thin) {
+        switch (w.KS) {
+            case 3: return dispatch_thin_nt<T, 3>(ctx, p, w.NT, nct, st);
+            case 9: return dispatch_thin_nt<T, 9>(ctx, p, w.NT, nct, st);
+        }
+    } else {
+        if (w.KS == 1 && w.KGPT == 4) return dispatch_wide_nt<T, 1, 4>(ctx, p, w.NT, nct, st);
+        if (w.KS == 1 && w.KGPT == 2) return dispatch_wide_nt<T, 1, 2>(ctx, p, w.NT, nct, st);
+        if (w.KS == 3 && w.KGPT == 2) return dispatch_wide_nt<T, 3, 2>(ctx, p, w.NT, nct, st);
+        if (w.KS == 5 && w.KGPT == 2 && w.NT == 1) return launch_wide<T, 5, 2, 1>(ctx, p, nct, st);
+    }
+    return ctx->fail(SR_ERR_INVALID, "conv: unsupported kernel size " + std::to_string(w.KS));
+}
+
+inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS, int Cin, int Cout, int dtype,
+                      ConvWeights* out) {
+    if (dtype != SR_DTYPE_BF16 && dtype != SR_DTYPE_F32) return ctx->fail(SR_ERR_INVALID, "conv: dtype must be f32 or bf16");
+    if (KS != 1 && KS != 3 && KS != 5 && KS != 9) return ctx->fail(SR_ERR_INVALID, "conv: kernel size must be 1,3,5 or 9");
+    const int esz = dtype_size(dtype), E = 16 / esz;
+    ConvWeights w;
+    w.dtype = dtype; w.KS = KS; w.Cin = Cin; w.Cout = Cout;
+    w.CoutP = round_up(Cout, 32);
+    const int nb = w.CoutP / 32;
+    w.NT = (nb % 2 == 0) ? 2 : (nb % 3 == 0 ? 3 : 1);
+    if (KS == 5 && !(Cin <= E)) w.NT = 1;   // 25 taps of weights: keep the LDS stage small
+    const int nct = nb / w.NT, ntap = KS * KS;
+    w.thin = Cin <= E;
+    if (!w.thin && KS == 9) return ctx->fail(SR_ERR_INVALID, "conv: 9x9 supported for <= one 16-byte channel slice only");
+    std::vector<char> host;
+    auto put = [&](size_t idx, float v) {
+        if (dtype == SR_DTYPE_F32) reinterpret_cast<float*>(host.data())[idx] = v;
+        else reinterpret_cast<uint16_t*>(host.data())[idx] = f32_to_bf16_host(v);
+    };
+    auto W = [&](int tap, int ci, int co) -> float {
+        if (tap >= ntap || ci >= Cin || co >= Cout) return 0.f;
+        return hwio[((size_t)tap * Cin + ci) * Cout + co];
+    };
+    if (w.thin) {
+        w.CinP = E; w.KGPT = 0;
+        const int KGT = (ntap + 1) / 2;
+        w.nchunks = KGT;
+        host.assign((size_t)nct * KGT * w.NT * 1024, 0);
+        size_t idx = 0;
+        for (int ct = 0; ct < nct; ++ct)
+            for (int g = 0; g < KGT; ++g)
+                for (int n = 0; n < w.NT; ++n)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < E; ++j, ++idx)
+                            put(idx, W(2 * g + (lane >> 5), j, (ct * w.NT + n) * 32 + (lane & 31)));
+    } else {
+        w.KGPT = (KS == 1 && (round_up(Cin, 4 * E) * esz) % 128 == 0) ? 4 : 2;
+        const int chunkE = w.KGPT * 2 * E;
+        w.CinP = round_up(Cin, chunkE);
+        w.nchunks = w.CinP / chunkE;
+        host.assign((size_t)nct * w.nchunks * ntap * w.KGPT * w.NT * 1024, 0);
+        size_t idx = 0;
+        for (int ct = 0; ct < nct; ++ct)
+            for (int ch = 0; ch < w.nchunks; ++ch)
+                for (int tap = 0; tap < ntap; ++tap)
+                    for (int kg = 0; kg < w.KGPT; ++kg)
+                        for (int n = 0; n < w.NT; ++n)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < E; ++j, ++idx)
+                                    put(idx, W(tap, ch * chunkE + kg * 2 * E + (lane >> 5) * E + j, (ct * w.NT + n) * 32 + (lane & 31)));
+    }
+    w.bytes = host.size();
+    w.w = ctx->dalloc(w.bytes);
+    if (!w.w) return SR_ERR_OOM;
+    w.bias = static_cast<float*>(ctx->dalloc(sizeof(float) * w.CoutP));
+    if (!w.bias) { ctx->dfree(w.w); return SR_ERR_OOM; }
+    std::vector<float> hb(w.CoutP, 0.f);
+    if (bias) for (int i = 0; i < Cout; ++i) hb[i] = bias[i];
+    SR_HIP(ctx, hipMemcpy(w.w, host.data(), w.bytes, hipMemcpyHostToDevice));
+    SR_HIP(ctx, hipMemcpy(w.bias, hb.data(), sizeof(float) * w.CoutP, hipMemcpyHostToDevice));
+    *out = w;
+    return SR_OK;
+}
+
+void conv_free_weights(sr_ctx* ctx, ConvWeights* w) {
+    if (w->w) ctx->dfree(w->w);
+    if (w->bias) ctx->dfree(w->bias);
+    w->w = nullptr; w->bias = nullptr;
+}
+
+int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W, void* y, int64_t y_cs, int y_coff,
+                const ConvEpilogue& ep, hipStream_t st) {
+    if (B <= 0 || H <= 0 || W <= 0) return ctx->fail(SR_ERR_INVALID, "conv: empty tensor");
+    const int esz = dtype_size(w.dtype);
+    if ((x.cs * esz) % 16 != 0 || (x.coff * esz) % 16 != 0 || ((uintptr_t)x.p % 16) != 0)
+        return ctx->fail(SR_ERR_INVALID, "conv: input view must be 16-byte aligned per pixel");
+    if (x.cs - x.coff < w.CinP) return ctx->fail(SR_ERR_INVALID, "conv: input view exposes fewer channels than the packed Cin");
+    if ((int64_t)H * W * x.cs >= (int64_t)1 << 31) return ctx->fail(SR_ERR_INVALID, "conv: image too large for 32-bit offsets");
+    const int r = ep.d2s_r < 1 ? 1 : ep.d2s_r;
+    if (w.Cout % (r * r) != 0) return ctx->fail(SR_ERR_INVALID, "conv: Cout not divisible by d2s block^2");
+    ConvParams p;
+    p.in = static_cast<const char*>(x.p); p.in_cs = x.cs; p.in_coff = x.coff;
+    p.w = static_cast<const char*>(w.w); p.bias = w.bias;
+    p.out = static_cast<char*>(y); p.out_cs = y_cs; p.out_coff = y_coff;
+    p.out_f32 = (ep.out_f32 || w.dtype == SR_DTYPE_F32) ? 1 : 0;
+    p.s1 = static_cast<const char*>(ep.skip1.p); p.s1_cs = ep.skip1.cs; p.s1_coff = ep.skip1.coff; p.beta1 = ep.beta1;
+    p.s2 = static_cast<const char*>(ep.skip2.p); p.s2_cs = ep.skip2.cs; p.s2_coff = ep.skip2.coff; p.beta2 = ep.beta2;
+    p.alpha = ep.alpha; p.act = ep.act; p.clip = ep.clip01; p.r = r; p.Cd = w.Cout / (r * r);
+    p.B = B; p.H = H; p.W = W; p.Cout = w.Cout; p.nchunks = w.nchunks; p.tilesX = p.tilesY = 0;
+    const int osz = p.out_f32 ? 4 : esz;
+    bool vec = (y_cs % 4 == 0) && (y_coff % 4 == 0) && ((uintptr_t)y % (4 * osz) == 0) && (p.Cd % 4 == 0);
+    if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);
+    if (p.s2) vec = vec && (p.s2_cs % 4 == 0) && (p.s2_coff % 4 == 0) && ((uintptr_t)p.s2 % (4 * esz) == 0);
+    p.vec = vec ? 1 : 0;
+    const int nct = w.CoutP / 32 / w.NT;
+    if (w.dtype == SR_DTYPE_BF16) return dispatch<bf16_t>(ctx, w, p, nct, st);
+    return dispatch<float>(ctx, w, p, nct, st);
+}

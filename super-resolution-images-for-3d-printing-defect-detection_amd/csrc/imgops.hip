@@ -1,0 +1,446 @@
+// imgops.hip -- the HBM-bound kernels either side of the conv stacks: dtype/channel padding,
+// bicubic resize (OpenCV INTER_CUBIC semantics), PSNR / SSIM (tf.image semantics), patch
+// extraction with reflect padding, overlap-add reconstruction, max-pool, global average pool,
+// dense head + softmax.  Each is priced against HBM bytes in DESIGN.md; none is GEMM-shaped.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const void* p, int64_t i);
+template <> __device__ __forceinline__ float ldf<float>(const void* p, int64_t i) { return static_cast<const float*>(p)[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const void* p, int64_t i) { return (float)static_cast<const bf16_t*>(p)[i]; }
+template <> __device__ __forceinline__ float ldf<uint8_t>(const void* p, int64_t i) { return (float)static_cast<const uint8_t*>(p)[i]; }
+template <typename T> __device__ __forceinline__ void stf(void* p, int64_t i, float v);
+template <> __device__ __forceinline__ void stf<float>(void* p, int64_t i, float v) { static_cast<float*>(p)[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(void* p, int64_t i, float v) { static_cast<bf16_t*>(p)[i] = (bf16_t)v; }
+
+__device__ __forceinline__ float ld_dt(const void* p, int64_t i, int dt) {
+    return dt == SR_DTYPE_F32 ? ldf<float>(p, i) : (dt == SR_DTYPE_BF16 ? ldf<bf16_t>(p, i) : ldf<uint8_t>(p, i));
+}
+__device__ __forceinline__ void st_dt(void* p, int64_t i, float v, int dt) {
+    if (dt == SR_DTYPE_F32) stf<float>(p, i, v); else stf<bf16_t>(p, i, v);
+}
+
+// ---------------------------------------------------------------------------------- convert + pad
+__global__ void convert_pad_kernel(const void* x, int in_dt, int64_t npix, int C, void* y, int out_dt, int Cp, float mul, float add) {
+    const int64_t n = npix * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / Cp;
+        const int c = (int)(i - pix * Cp);
+        const float v = c < C ? ld_dt(x, pix * C + c, in_dt) * mul + add : 0.f;
+        st_dt(y, i, v, out_dt);
+    }
+}
+
+// ---------------------------------------------------------------------------------- maxpool 2x2 (VALID, floor)
+__global__ void maxpool2_kernel(const void* x, int dt, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t n = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int c = (int)(t % C); t /= C;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const int64_t base = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * x_cs + c;
+        const float v = fmaxf(fmaxf(ld_dt(x, base, dt), ld_dt(x, base + x_cs, dt)),
+                              fmaxf(ld_dt(x, base + (int64_t)W * x_cs, dt), ld_dt(x, base + (int64_t)W * x_cs + x_cs, dt)));
+        st_dt(y, (((int64_t)b * Ho + oy) * Wo + ox) * y_cs + c, v, dt);
+    }
+}
+
+// ---------------------------------------------------------------------------------- global average pool -> fp32
+__global__ void gap_kernel(const void* x, int dt, int HW, int C, int64_t x_cs, float* y) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < HW; ++i) s += ld_dt(x, ((int64_t)b * HW + i) * x_cs + c, dt);
+        y[(int64_t)b * C + c] = s / (float)HW;
+    }
+}
+
+// ---------------------------------------------------------------------------------- dense (+relu | softmax)
+__global__ void dense_kernel(const float* x, const float* w, const float* bias, int In, int Out, int act, float* y, int y_dt,
+                             void* y_typed) {
+    extern __shared__ float sm[];   // [Out] logits + [256] scratch
+    float* logits = sm;
+    float* red = sm + Out;
+    const int b = blockIdx.x;
+    const float* xb = x + (int64_t)b * In;
+    for (int o = threadIdx.x; o < Out; o += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < In; ++i) s += xb[i] * w[(int64_t)i * Out + o];
+        s += bias ? bias[o] : 0.f;
+        if (act == SR_ACT_RELU) s = fmaxf(s, 0.f);
+        logits[o] = s;
+    }
+    __syncthreads();
+    if (act == 100) {
+        float mx = -INFINITY;
+        for (int o = threadIdx.x; o < Out; o += blockDim.x) mx = fmaxf(mx, logits[o]);
+        red[threadIdx.x] = mx;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+        mx = red[0];
+        __syncthreads();
+        float sum = 0.f;
+        for (int o = threadIdx.x; o < Out; o += blockDim.x) { const float e = expf(logits[o] - mx); logits[o] = e; sum += e; }
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+        sum = red[0];
+        for (int o = threadIdx.x; o < Out; o += blockDim.x) logits[o] /= sum;
+        __syncthreads();
+    }
+    for (int o = threadIdx.x; o < Out; o += blockDim.x) {
+        if (y) y[(int64_t)b * Out + o] = logits[o];
+        if (y_typed) st_dt(y_typed, (int64_t)b * Out + o, logits[o], y_dt);
+    }
+}
+
+// ---------------------------------------------------------------------------------- bicubic (OpenCV INTER_CUBIC)
+// reference: cv2.resize float path (classic_algorithms.py:11-13, SRCNN_model.py:191): half-pixel
+// centres, Keys a=-0.75 (three polynomials + 1-sum), replicate border, horizontal then vertical.
+__device__ __forceinline__ void cubic_w(float x, float w[4]) {
+    const float A = -0.75f;
+    w[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    w[2] = ((A + 2.f) * (1.f - x) - (A + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
+}
+__device__ __forceinline__ void cubic_axis(int d, double scale, int n, int idx[4], float w[4]) {
+    const float f = (float)(((double)d + 0.5) * scale - 0.5);
+    const int s = (int)floorf(f);
+    cubic_w(f - (float)s, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) idx[k] = min(max(s - 1 + k, 0), n - 1);
+}
+
+__global__ void bicubic_f32_kernel(const float* x, int B, int H, int W, int C, int oH, int oW, double sy, double sx, void* y,
+                                   int out_dt, int64_t y_cs) {
+    const int64_t n = (int64_t)B * oH * oW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % oW);
+        const int oy = (int)((i / oW) % oH);
+        const int b = (int)(i / ((int64_t)oW * oH));
+        int ix[4], iy[4];
+        float wx[4], wy[4];
+        cubic_axis(ox, sx, W, ix, wx);
+        cubic_axis(oy, sy, H, iy, wy);
+        const float* xb = x + (int64_t)b * H * W * C;
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const float* row = xb + (int64_t)iy[ky] * W * C + c;
+                float hsum = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) hsum += row[(int64_t)ix[kx] * C] * wx[kx];
+                acc += hsum * wy[ky];
+            }
+            st_dt(y, i * y_cs + c, acc, out_dt);
+        }
+        for (int c = C; c < y_cs; ++c) st_dt(y, i * y_cs + c, 0.f, out_dt);   // zero the pad channels of a padded view
+    }
+}
+
+// uint8 fixed-point path: 11-bit coefficients, int accumulation, rounding >> 22, saturate.
+__global__ void bicubic_u8_kernel(const uint8_t* x, int B, int H, int W, int C, int oH, int oW, double sy, double sx, uint8_t* y) {
+    const int64_t n = (int64_t)B * oH * oW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % oW);
+        const int oy = (int)((i / oW) % oH);
+        const int b = (int)(i / ((int64_t)oW * oH));
+        int ix[4], iy[4], iwx[4], iwy[4];
+        float wx[4], wy[4];
+        cubic_axis(ox, sx, W, ix, wx);
+        cubic_axis(oy, sy, H, iy, wy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            iwx[k] = min(max((int)rintf(wx[k] * 2048.f), -32768), 32767);
+            iwy[k] = min(max((int)rintf(wy[k] * 2048.f), -32768), 32767);
+        }
+        const uint8_t* xb = x + (int64_t)b * H * W * C;
+        for (int c = 0; c < C; ++c) {
+            int acc = 0;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const uint8_t* row = xb + (int64_t)iy[ky] * W * C + c;
+                int hsum = 0;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) hsum += (int)row[(int64_t)ix[kx] * C] * iwx[kx];
+                acc += hsum * iwy[ky];
+            }
+            acc = (acc + (1 << 21)) >> 22;
+            y[i * C + c] = (uint8_t)min(max(acc, 0), 255);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- reductions
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
+// stage 1: partial[b][blk] = sum over a slice of (a-b)^2
+__global__ void sqdiff_partial_kernel(const float* a, const float* b, int64_t n_per_image, float* partial) {
+    __shared__ float red[16];
+    const int img = blockIdx.y;
+    const float* pa = a + (int64_t)img * n_per_image;
+    const float* pb = b + (int64_t)img * n_per_image;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_image; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = pa[i] - pb[i];
+        s += d * d;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[(int64_t)img * gridDim.x + blockIdx.x] = s;
+}
+// stage 2 (fixed order -> reproducible): mode 0 = psnr, 1 = plain mean, 2 = ssim mean
+__global__ void finish_kernel(const float* partial, int nblk, double count, float max_val, int mode, float* out) {
+    __shared__ double red[256];
+    const int img = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += (double)partial[(int64_t)img * nblk + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const float mean = (float)(red[0] / count);
+        // tf.image.psnr: 20*log(max)/log(10) - 10/log(10)*log(mse)
+        out[img] = mode == 0 ? (20.f * logf(max_val) / logf(10.f) - 10.f / logf(10.f) * logf(mean)) : mean;
+    }
+}
+
+// SSIM (tf.image.ssim: 11x11 gaussian sigma 1.5, VALID, per channel, k1=.01 k2=.03).
+struct GaussW { float g[11]; };
+constexpr int ST = 16, SWIN = ST + 10;
+__global__ void __launch_bounds__(256) ssim_partial_kernel(const float* a, const float* b, int H, int W, int C, GaussW gw, float c1,
+                                                           float c2, int tilesX, float* partial) {
+    __shared__ float ta[SWIN][SWIN + 1], tb[SWIN][SWIN + 1];
+    __shared__ float hz[4][SWIN][ST + 1];
+    __shared__ float red[16];
+    const int img = blockIdx.y;
+    const int ty0 = (blockIdx.x / tilesX) * ST, tx0 = (blockIdx.x % tilesX) * ST;
+    const int oH = H - 10, oW = W - 10;
+    const int tid = threadIdx.x, ty = tid / ST, tx = tid % ST;
+    float total = 0.f;
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+        for (int u = tid; u < SWIN * SWIN; u += 256) {
+            const int py = u / SWIN, px = u % SWIN;
+            const int gy = min(ty0 + py, H - 1), gx = min(tx0 + px, W - 1);
+            const int64_t idx = (((int64_t)img * H + gy) * W + gx) * C + c;
+            ta[py][px] = a[idx];
+            tb[py][px] = b[idx];
+        }
+        __syncthreads();
+        for (int u = tid; u < SWIN * ST; u += 256) {
+            const int py = u / ST, px = u % ST;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float va = ta[py][px + k], vb = tb[py][px + k], g = gw.g[k];
+                s0 += g * va; s1 += g * vb; s2 += g * (va * vb); s3 += g * (va * va + vb * vb);
+            }
+            hz[0][py][px] = s0; hz[1][py][px] = s1; hz[2][py][px] = s2; hz[3][py][px] = s3;
+        }
+        __syncthreads();
+        if (ty0 + ty < oH && tx0 + tx < oW) {
+            float m0 = 0.f, m1 = 0.f, sab = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float g = gw.g[k];
+                m0 += g * hz[0][ty + k][tx]; m1 += g * hz[1][ty + k][tx]; sab += g * hz[2][ty + k][tx]; sq += g * hz[3][ty + k][tx];
+            }
+            const float num0 = m0 * m1 * 2.f, den0 = m0 * m0 + m1 * m1;
+            const float lum = (num0 + c1) / (den0 + c1);
+            const float cs = (sab * 2.f - num0 + c2) / (sq - den0 + c2);
+            total += lum * cs;
+        }
+    }
+    total = block_sum(total, red);
+    if (tid == 0) partial[(int64_t)img * gridDim.x + blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------- patches
+// reflect index for bottom/right padding (np.pad mode='reflect': no edge repeat): y >= n -> 2(n-1) - y
+__device__ __forceinline__ int reflect(int y, int n) { return y < n ? y : 2 * (n - 1) - y; }
+
+__global__ void extract_patches_kernel(const float* img, int H, int W, int C, int patch, int stride, float mul, float add, int out_dt,
+                                       void* out, int ny, int nx) {
+    const int64_t n = (int64_t)ny * nx * patch * patch * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int c = (int)(t % C); t /= C;
+        const int px = (int)(t % patch); t /= patch;
+        const int py = (int)(t % patch); t /= patch;
+        const int jx = (int)(t % nx);
+        const int jy = (int)(t / nx);
+        const int y = reflect(jy * stride + py, H), x = reflect(jx * stride + px, W);
+        st_dt(out, i, img[((int64_t)y * W + x) * C + c] * mul + add, out_dt);
+    }
+}
+
+// gather form of the reference's scatter-add: same summation order (patches in row-major position order)
+__global__ void overlap_add_kernel(const void* patches, int in_dt, int H, int W, int C, int patch, int stride, int scale, float mul,
+                                   float add, int ny, int nx, float* out) {
+    const int oH = H * scale, oW = W * scale, ps = patch * scale, ss = stride * scale;
+    const int64_t n = (int64_t)oH * oW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int c = (int)(t % C); t /= C;
+        const int x = (int)(t % oW);
+        const int y = (int)(t / oW);
+        const int jy1 = min(y / ss, ny - 1), jx1 = min(x / ss, nx - 1);
+        const int jy0 = max(0, (y - ps + ss) / ss), jx0 = max(0, (x - ps + ss) / ss);
+        float sum = 0.f, cnt = 0.f;
+        for (int jy = jy0; jy <= jy1; ++jy) {
+            const int py = y - jy * ss;
+            if (py < 0 || py >= ps) continue;
+            for (int jx = jx0; jx <= jx1; ++jx) {
+                const int px = x - jx * ss;
+                if (px < 0 || px >= ps) continue;
+                const int64_t idx = ((((int64_t)jy * nx + jx) * ps + py) * ps + px) * C + c;
+                sum += ld_dt(patches, idx, in_dt) * mul + add;
+                cnt += 1.f;
+            }
+        }
+        const float v = cnt != 0.f ? sum / cnt : 0.f;
+        out[i] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+}
+
+inline unsigned grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    const int64_t cap = 256 * 8 * 4;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+// ================================================================================================
+int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype, int Cp, float mul,
+                       float add, hipStream_t st) {
+    if (npix <= 0) return SR_OK;
+    hipLaunchKernelGGL(convert_pad_kernel, dim3(grid_for(npix * Cp)), dim3(256), 0, st, x, in_dtype, npix, C, y, out_dtype, Cp, mul, add);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs, hipStream_t st) {
+    const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+    if (n <= 0) return ctx->fail(SR_ERR_INVALID, "maxpool: output would be empty");
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, dtype, B, H, W, C, x_cs, y, y_cs);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int gap_launch(sr_ctx* ctx, int dtype, const void* x, int B, int HW, int C, int64_t x_cs, float* y, hipStream_t st) {
+    hipLaunchKernelGGL(gap_kernel, dim3(B), dim3(256), 0, st, x, dtype, HW, C, x_cs, y);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int dense_launch(sr_ctx* ctx, const float* x, const float* w, const float* bias, int B, int In, int Out, int act, float* y, int y_dtype,
+                 void* y_typed, hipStream_t st) {
+    if (Out > 8192) return ctx->fail(SR_ERR_INVALID, "dense: Out too large");
+    hipLaunchKernelGGL(dense_kernel, dim3(B), dim3(256), sizeof(float) * (Out + 256), st, x, w, bias, In, Out, act, y, y_dtype, y_typed);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int bicubic_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, void* y, int out_dtype,
+                   int64_t y_cs, hipStream_t st) {
+    if (B <= 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0) return ctx->fail(SR_ERR_INVALID, "bicubic: empty tensor");
+    // OpenCV: inv_scale = dsize/ssize (double), scale = 1./inv_scale
+    const double sy = 1.0 / ((double)outH / (double)H), sx = 1.0 / ((double)outW / (double)W);
+    const int64_t n = (int64_t)B * outH * outW;
+    if (dtype == SR_DTYPE_F32)
+        hipLaunchKernelGGL(bicubic_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const float*>(x), B, H, W, C, outH, outW,
+                           sy, sx, y, out_dtype, y_cs);
+    else if (dtype == SR_DTYPE_U8)
+        hipLaunchKernelGGL(bicubic_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const uint8_t*>(x), B, H, W, C, outH, outW,
+                           sy, sx, static_cast<uint8_t*>(y));
+    else return ctx->fail(SR_ERR_INVALID, "bicubic: dtype must be f32 or u8");
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+static int reduce_scratch(sr_ctx* ctx, size_t floats, float** out) {
+    void* p = ctx->scratch(floats * sizeof(float));   // ctx-owned, grown on demand, reused by later calls on the same stream
+    if (!p) return SR_ERR_OOM;
+    *out = static_cast<float*>(p);
+    return SR_OK;
+}
+
+int psnr_launch(sr_ctx* ctx, const float* a, const float* b, int B, int64_t n_per_image, float max_val, float* out, hipStream_t st) {
+    if (B <= 0 || n_per_image <= 0) return ctx->fail(SR_ERR_INVALID, "psnr: empty tensor");
+    const int nblk = (int)grid_for(n_per_image) > 1024 ? 1024 : (int)grid_for(n_per_image);
+    float* partial;
+    int rc = reduce_scratch(ctx, (size_t)B * nblk, &partial);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(nblk, B), dim3(256), 0, st, a, b, n_per_image, partial);
+    hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(256), 0, st, partial, nblk, (double)n_per_image, max_val, 0, out);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int mse_launch(sr_ctx* ctx, const float* a, const float* b, int64_t n, float* out, hipStream_t st) {
+    if (n <= 0) return ctx->fail(SR_ERR_INVALID, "mse: empty tensor");
+    const int nblk = (int)grid_for(n) > 1024 ? 1024 : (int)grid_for(n);
+    float* partial;
+    int rc = reduce_scratch(ctx, (size_t)nblk, &partial);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(nblk, 1), dim3(256), 0, st, a, b, n, partial);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partial, nblk, (double)n, 1.f, 1, out);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int ssim_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float max_val, float* out, hipStream_t st) {
+    if (B <= 0 || C <= 0) return ctx->fail(SR_ERR_INVALID, "ssim: empty tensor");
+    if (H < 11 || W < 11) return ctx->fail(SR_ERR_INVALID, "ssim: H and W must be >= 11 (filter_size)");
+    GaussW gw;
+    double g[11], s = 0.0;
+    for (int i = 0; i < 11; ++i) { const double x = i - 5.0; g[i] = exp(-(x * x) / (2.0 * 1.5 * 1.5)); s += g[i]; }
+    for (int i = 0; i < 11; ++i) gw.g[i] = (float)(g[i] / s);
+    const int oH = H - 10, oW = W - 10;
+    const int tilesX = (oW + ST - 1) / ST, tilesY = (oH + ST - 1) / ST;
+    const int nblk = tilesX * tilesY;
+    float* partial;
+    int rc = reduce_scratch(ctx, (size_t)B * nblk, &partial);
+    if (rc) return rc;
+    const float c1 = (0.01f * max_val) * (0.01f * max_val), c2 = (0.03f * max_val) * (0.03f * max_val);
+    hipLaunchKernelGGL(ssim_partial_kernel, dim3(nblk, B), dim3(256), 0, st, a, b, H, W, C, gw, c1, c2, tilesX, partial);
+    hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(256), 0, st, partial, nblk, (double)oH * oW * C, 1.f, 2, out);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int extract_patches_launch(sr_ctx* ctx, const float* img, int H, int W, int C, int patch, int stride, float mul, float add, int out_dtype,
+                           void* out, int ny, int nx, hipStream_t st) {
+    const int64_t n = (int64_t)ny * nx * patch * patch * C;
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(extract_patches_kernel, dim3(grid_for(n)), dim3(256), 0, st, img, H, W, C, patch, stride, mul, add, out_dtype, out,
+                       ny, nx);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int overlap_add_launch(sr_ctx* ctx, const void* patches, int in_dtype, int H, int W, int C, int patch, int stride, int scale, float mul,
+                       float add, int ny, int nx, float* out, hipStream_t st) {
+    const int64_t n = (int64_t)H * scale * W * scale * C;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, patches, in_dtype, H, W, C, patch, stride, scale, mul, add,
+                       ny, nx, out);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}

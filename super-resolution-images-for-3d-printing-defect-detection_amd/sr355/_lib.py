@@ -1,0 +1,74 @@
+"""ctypes binding of libsr355.so (C ABI: include/sr355.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared object is missing
+the import of anything that needs it raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsr355.so")
+
+SR_OK = 0
+SR_ERR_INVALID, SR_ERR_HIP, SR_ERR_OOM, SR_ERR_STATE, SR_ERR_NAME, SR_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
+DTYPE_F32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2
+MODEL_SRCNN, MODEL_EDSR, MODEL_ESRGAN_G, MODEL_VGG16 = 0, 1, 2, 3
+ACT_LINEAR, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+WEIGHT_KERNEL, WEIGHT_BIAS = 0, 1
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("compute_dtype", C.c_int32), ("scale_factor", C.c_int32), ("channels", C.c_int32),
+                ("num_blocks", C.c_int32), ("num_filters", C.c_int32), ("growth_channels", C.c_int32),
+                ("res_scaling", C.c_float), ("num_classes", C.c_int32), ("use_attention", C.c_int32)]
+
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+_fp = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); every symbol include/sr355.h declares
+SIGNATURES = {
+    "sr_init": (_i, [_i, C.POINTER(_vp)]),
+    "sr_destroy": (None, [_vp]),
+    "sr_last_error": (C.c_char_p, [_vp]),
+    "sr_mem_info": (_i, [_vp, _i64p, _i64p]),
+    "sr_last_forward_ms": (_i, [_vp, _fp]),
+    "sr_model_create": (_i, [_vp, _i, C.POINTER(ModelCfg), C.POINTER(_vp)]),
+    "sr_model_destroy": (None, [_vp]),
+    "sr_model_num_params": (_i, [_vp]),
+    "sr_model_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), _i64p, C.POINTER(_i)]),
+    "sr_model_set_weight": (_i, [_vp, C.c_char_p, _i, _fp, _i64p, _i]),
+    "sr_model_finalize": (_i, [_vp]),
+    "sr_model_output_shape": (_i, [_vp, _i, _i, _i, _i, _i64p]),
+    "sr_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "sr_conv2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _f, _vp, _f, _vp, _f, _i, _i, _vp, _vp]),
+    "sr_self_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
+    "sr_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sr_psnr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "sr_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "sr_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "sr_extract_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i64, C.POINTER(_i), _vp]),
+    "sr_overlap_add": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsr355.so (once) and declare the prototypes.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"libsr355.so not found at {LIB_PATH}: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C <package>/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

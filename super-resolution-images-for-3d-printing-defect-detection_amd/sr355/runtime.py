@@ -1,0 +1,258 @@
+"""Host runtime over the C ABI: one Context per GPU, torch-ROCm tensors as device-memory containers.
+
+Nothing here computes: every numeric operation is a call into libsr355.so on the tensor's device
+and the current torch stream.  Errors coming back over the ABI are raised as the exception types
+the reference raises at the same call sites (ValueError / RuntimeError / KeyError / MemoryError).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class Sr355Error(RuntimeError):
+    pass
+
+
+_EXC = {L.SR_ERR_INVALID: ValueError, L.SR_ERR_HIP: Sr355Error, L.SR_ERR_OOM: MemoryError,
+        L.SR_ERR_STATE: RuntimeError, L.SR_ERR_NAME: KeyError, L.SR_ERR_CAPACITY: ValueError}
+
+_TORCH2DT = {torch.float32: L.DTYPE_F32, torch.bfloat16: L.DTYPE_BF16, torch.uint8: L.DTYPE_U8}
+_DT2TORCH = {v: k for k, v in _TORCH2DT.items()}
+
+
+def dtype_code(dt):
+    if isinstance(dt, str):
+        dt = {"f32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+              "u8": torch.uint8}[dt]
+    return _TORCH2DT[dt]
+
+
+def _fptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _np32(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class Context:
+    """sr_ctx wrapper; `Context.get(i)` returns the process-wide context of GPU i."""
+    _instances = {}
+
+    @classmethod
+    def get(cls, device=None):
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("sr355 needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+            device = torch.cuda.current_device()
+        if isinstance(device, torch.device):
+            device = device.index if device.index is not None else torch.cuda.current_device()
+        if device not in cls._instances:
+            cls._instances[device] = cls(device)
+        return cls._instances[device]
+
+    def __init__(self, device):
+        self.lib = L.load()
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.sr_init(self.device, C.byref(h))
+        if rc != L.SR_OK:
+            raise Sr355Error(f"sr_init(device={device}) failed with {rc} (no usable GPU?)")
+        self.h = h
+        self.torch_device = torch.device("cuda", self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def check(self, rc):
+        if rc != L.SR_OK:
+            msg = self.lib.sr_last_error(self.h).decode("utf-8", "replace")
+            raise _EXC.get(rc, Sr355Error)(msg)
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.torch_device).cuda_stream)
+
+    def to_device(self, a, dtype=None):
+        """NumPy array or tensor -> contiguous tensor on this GPU (the reference hands NumPy arrays to predict)."""
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.to(self.torch_device, non_blocking=False).contiguous()
+
+    def empty(self, shape, dtype=torch.float32):
+        return torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=self.torch_device)
+
+    def mem_info(self):
+        cur, peak = C.c_int64(), C.c_int64()
+        self.check(self.lib.sr_mem_info(self.h, C.byref(cur), C.byref(peak)))
+        return {"current": cur.value, "peak": peak.value}
+
+    def last_forward_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.sr_last_forward_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------------ single ops
+    def conv2d(self, x, w, b=None, act="linear", alpha=1.0, skip1=None, beta1=0.0, skip2=None, beta2=0.0,
+               clip01=False, d2s=1):
+        """Keras Conv2D(padding='same') + fused epilogue; x NHWC tensor (f32/bf16), w HWIO NumPy."""
+        w = _np32(w)
+        b = _np32(b)
+        kh, kw, cin, cout = w.shape
+        B, H, W, Cx = x.shape
+        if Cx != cin:
+            raise ValueError("conv2d: input channels do not match the kernel")
+        r = max(1, int(d2s))
+        y = self.empty((B, H * r, W * r, cout // (r * r)), x.dtype)
+        actc = {"linear": L.ACT_LINEAR, None: L.ACT_LINEAR, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH}[act]
+        self.check(self.lib.sr_conv2d(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, cin, _fptr(w), _fptr(b), kh, kw, cout,
+                                      actc, float(alpha), None if skip1 is None else skip1.data_ptr(), float(beta1),
+                                      None if skip2 is None else skip2.data_ptr(), float(beta2), int(bool(clip01)), r,
+                                      y.data_ptr(), self.stream()))
+        return y
+
+    def self_attention(self, x, wf, bf, wg, bg, wh, bh, wv, bv):
+        B, H, W, Cx = x.shape
+        arrs = [_np32(a) for a in (wf, bf, wg, bg, wh, bh, wv, bv)]
+        y = torch.empty_like(x)
+        self.check(self.lib.sr_self_attention(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, Cx, *[_fptr(a) for a in arrs],
+                                              y.data_ptr(), self.stream()))
+        return y
+
+    def bicubic(self, x, out_h, out_w):
+        B, H, W, Cx = x.shape
+        y = self.empty((B, out_h, out_w, Cx), x.dtype)
+        self.check(self.lib.sr_bicubic(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, Cx, int(out_h), int(out_w), y.data_ptr(),
+                                       self.stream()))
+        return y
+
+    def _metric(self, fn, a, b, max_val):
+        if a.shape != b.shape or a.dim() != 4:
+            raise ValueError("metric inputs must be two [B,H,W,C] tensors of the same shape")
+        B, H, W, Cx = a.shape
+        out = self.empty((B,), torch.float32)
+        if B:
+            self.check(fn(self.h, a.data_ptr(), b.data_ptr(), B, H, W, Cx, float(max_val), out.data_ptr(), self.stream()))
+        return out
+
+    def psnr(self, a, b, max_val=1.0):
+        return self._metric(self.lib.sr_psnr, a, b, max_val)
+
+    def ssim(self, a, b, max_val=1.0):
+        return self._metric(self.lib.sr_ssim, a, b, max_val)
+
+    def mse(self, a, b):
+        out = self.empty((1,), torch.float32)
+        self.check(self.lib.sr_mse(self.h, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), self.stream()))
+        return out
+
+    def num_patches(self, H, W, C_, patch, stride):
+        n = C.c_int()
+        self.check(self.lib.sr_extract_patches(self.h, None, H, W, C_, patch, stride, 1.0, 0.0, L.DTYPE_F32, None, 0, C.byref(n), None))
+        return n.value
+
+    def extract_patches(self, img, patch, stride, mul=1.0, add=0.0, out_dtype=torch.float32):
+        H, W, Cx = img.shape
+        n = self.num_patches(H, W, Cx, patch, stride)
+        out = self.empty((n, patch, patch, Cx), out_dtype)
+        cnt = C.c_int()
+        self.check(self.lib.sr_extract_patches(self.h, img.data_ptr(), H, W, Cx, patch, stride, float(mul), float(add),
+                                               dtype_code(out_dtype), out.data_ptr(), out.numel(), C.byref(cnt), self.stream()))
+        return out
+
+    def overlap_add(self, patches, H, W, patch, stride, scale=1, mul=1.0, add=0.0):
+        Cx = patches.shape[-1]
+        out = self.empty((H * scale, W * scale, Cx), torch.float32)
+        self.check(self.lib.sr_overlap_add(self.h, patches.data_ptr(), dtype_code(patches.dtype), H, W, Cx, patch, stride, scale,
+                                           float(mul), float(add), out.data_ptr(), self.stream()))
+        return out
+
+
+class Model:
+    """sr_model wrapper: build from the reference's setup_model() hyper-parameters, load Keras-named
+    weights, run forward on device tensors."""
+    KINDS = {"srcnn": L.MODEL_SRCNN, "edsr": L.MODEL_EDSR, "esrgan_g": L.MODEL_ESRGAN_G, "vgg16": L.MODEL_VGG16}
+
+    def __init__(self, kind, compute_dtype="f32", scale_factor=1, channels=3, num_blocks=0, num_filters=64,
+                 growth_channels=32, res_scaling=0.1, num_classes=2, use_attention=True, ctx=None):
+        self.ctx = ctx or Context.get()
+        self.kind = kind
+        self.compute_dtype = _DT2TORCH[dtype_code(compute_dtype)]
+        cfg = L.ModelCfg(dtype_code(compute_dtype), int(scale_factor), int(channels), int(num_blocks), int(num_filters),
+                         int(growth_channels), float(res_scaling), int(num_classes), int(bool(use_attention)))
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.sr_model_create(self.ctx.h, self.KINDS[kind], C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.sr_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def param_specs(self):
+        """[(keras_layer_name, 'kernel'|'bias', shape)] in graph order."""
+        lib = self.ctx.lib
+        out = []
+        for i in range(lib.sr_model_num_params(self.h)):
+            name, which, nd = C.c_char_p(), C.c_int(), C.c_int()
+            shape = (C.c_int64 * 4)()
+            self.ctx.check(lib.sr_model_param_info(self.h, i, C.byref(name), C.byref(which), shape, C.byref(nd)))
+            out.append((name.value.decode(), "bias" if which.value else "kernel", tuple(shape[:nd.value])))
+        return out
+
+    def layer_shapes(self):
+        """[(layer_name, kernel_shape)] -- one entry per Keras layer."""
+        return [(n, s) for n, w, s in self.param_specs() if w == "kernel"]
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for _, _, s in self.param_specs()))
+
+    def set_weights(self, weights):
+        """weights: {layer_name: (kernel, bias)} (conv HWIO, dense [in,out]).  Missing layers -> KeyError."""
+        lib = self.ctx.lib
+        for name, kshape in self.layer_shapes():
+            if name not in weights:
+                raise KeyError(f"weights for layer '{name}' missing")
+            k, b = weights[name]
+            for which, arr in ((L.WEIGHT_KERNEL, k), (L.WEIGHT_BIAS, b)):
+                a = _np32(arr)
+                shp = (C.c_int64 * a.ndim)(*a.shape)
+                self.ctx.check(lib.sr_model_set_weight(self.h, name.encode(), which, _fptr(a), shp, a.ndim))
+        self.ctx.check(lib.sr_model_finalize(self.h))
+        self.finalized = True
+
+    def output_shape(self, B, H, W, Cx):
+        s = (C.c_int64 * 4)()
+        self.ctx.check(self.ctx.lib.sr_model_output_shape(self.h, B, H, W, Cx, s))
+        return tuple(s) if self.kind != "vgg16" else (s[0], s[1])
+
+    def forward(self, x, out=None):
+        """x [B,H,W,C] device tensor (f32, or bf16 for a bf16 model) -> output tensor of the same dtype."""
+        if x.dim() != 4:
+            raise ValueError("expected a [B,H,W,C] tensor")
+        x = x.contiguous()
+        B, H, W, Cx = x.shape
+        oshape = self.output_shape(B, H, W, Cx)
+        y = out if out is not None else self.ctx.empty(oshape, x.dtype)
+        self.ctx.check(self.ctx.lib.sr_forward(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, Cx, y.data_ptr(), y.numel(),
+                                               self.ctx.stream()))
+        return y
+
+    def predict(self, x, batch_size=32):
+        """keras Model.predict(x, batch_size): forward in chunks, outputs concatenated.  Accepts NumPy
+        (returns NumPy, as Keras does) or a device tensor (returns a device tensor)."""
+        is_np = not isinstance(x, torch.Tensor)
+        xt = self.ctx.to_device(x, torch.float32) if is_np else x
+        n = xt.shape[0]
+        oshape = self.output_shape(n, *xt.shape[1:])
+        y = self.ctx.empty(oshape, xt.dtype)
+        for i in range(0, n, max(1, int(batch_size))):
+            self.forward(xt[i:i + batch_size], out=y[i:i + batch_size])
+        if is_np:
+            return y.float().cpu().numpy()
+        return y
