@@ -87,3 +87,104 @@ def test_conv2d_depth_to_space_dcr(ctx, r, cout):
     got = ctx.conv2d(_dev(ctx, x, torch.float32), w, None, d2s=r).cpu().numpy()
     assert got.shape == ref.shape
     assert rel_l2(got, ref) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _sa_weights(rng, C=64):
+    mk = lambda ci, co: (rng.standard_normal((1, 1, ci, co)) / np.sqrt(ci)).astype(np.float32)
+    bias = lambda co: rng.uniform(-0.1, 0.1, co).astype(np.float32)
+    return [mk(C, C // 8), bias(C // 8), mk(C, C // 8), bias(C // 8), mk(C, C // 2), bias(C // 2), mk(C // 2, C), bias(C)]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("hw", [(24, 24), (48, 48), (13, 9), (1, 1), (11, 12)])   # N = 576, 2304, ragged 117, 1, 132
+def test_self_attention_matches_oracle(ctx, hw, dtype):
+    H, W = hw
+    rng = np.random.default_rng(H * 100 + W)
+    x = rng.standard_normal((2, H, W, 64)).astype(np.float32)
+    ws = _sa_weights(rng)
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    if dtype == "bf16":
+        x = round_to_bf16(x)
+        ws = [round_to_bf16(a) if a.ndim == 4 else a for a in ws]
+    ref = O.self_attention(x, *ws, dtype=np.float64)
+    got = ctx.self_attention(_dev(ctx, x, td), *ws).float().cpu().numpy()
+    err = rel_l2(got, ref)
+    assert err <= (2e-5 if dtype == "f32" else 2e-2), err
+
+
+def test_self_attention_forced_max_jump(ctx):
+    """Online-softmax rescale branch: spike one key so the running max jumps late in the key sweep."""
+    rng = np.random.default_rng(11)
+    H, W = 16, 16
+    x = (0.1 * rng.standard_normal((1, H, W, 64))).astype(np.float32)
+    x[0, 15, 3, :] = 6.0          # a late token with a huge projection
+    ws = _sa_weights(rng)
+    ref = O.self_attention(x, *ws, dtype=np.float64)
+    got = ctx.self_attention(_dev(ctx, x, torch.float32), *ws).cpu().numpy()
+    assert rel_l2(got, ref) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ image ops
+@pytest.mark.parametrize("shape,out", [((1, 64, 64, 3), (256, 256)), ((2, 23, 31, 3), (46, 62)), ((1, 239, 239, 3), (478, 478)),
+                                       ((1, 10, 10, 1), (37, 23))])
+def test_bicubic_f32(ctx, shape, out):
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 1, shape).astype(np.float32)
+    ref = O.bicubic_resize(x, out[0], out[1])
+    got = ctx.bicubic(_dev(ctx, x, torch.float32), out[0], out[1]).cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 2e-6
+
+
+def test_bicubic_u8_bit_exact(ctx):
+    rng = np.random.default_rng(4)
+    x = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    ref = O.bicubic_resize_u8(x, 256, 256)
+    got = ctx.bicubic(ctx.to_device(x[None], torch.uint8), 256, 256).cpu().numpy()[0]
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(4, 24, 24, 3), (2, 256, 256, 3), (1, 11, 40, 3), (3, 37, 53, 1)])
+def test_psnr_ssim(ctx, shape):
+    rng = np.random.default_rng(9)
+    a = rng.uniform(0, 1, shape).astype(np.float32)
+    b = np.clip(a + 0.05 * rng.standard_normal(shape), 0, 1).astype(np.float32)
+    da, db = _dev(ctx, a, torch.float32), _dev(ctx, b, torch.float32)
+    p = ctx.psnr(da, db).cpu().numpy()
+    s = ctx.ssim(da, db).cpu().numpy()
+    assert np.allclose(p, O.psnr(a, b, dtype=np.float64), atol=2e-4)          # dB
+    assert np.allclose(s, O.ssim(a, b, dtype=np.float64), atol=5e-5)
+    m = ctx.mse(da, db).cpu().numpy()[0]
+    assert np.isclose(m, np.mean((a.astype(np.float64) - b) ** 2), rtol=1e-5)
+
+
+def test_psnr_identical_is_inf_and_ssim_one(ctx):
+    a = _dev(ctx, np.random.default_rng(1).uniform(0, 1, (2, 24, 24, 3)), torch.float32)
+    assert torch.isinf(ctx.psnr(a, a)).all()
+    assert np.allclose(ctx.ssim(a, a).cpu().numpy(), 1.0, atol=1e-6)
+
+
+def test_ssim_too_small_raises(ctx):
+    a = _dev(ctx, np.zeros((1, 10, 24, 3)), torch.float32)
+    with pytest.raises(ValueError):
+        ctx.ssim(a, a)
+
+
+@pytest.mark.parametrize("hw,p,s,scale", [((239, 239), 24, 12, 2), ((512, 512), 48, 24, 4), ((100, 77), 33, 14, 1), ((48, 48), 48, 24, 2)])
+def test_extract_and_overlap_add(ctx, hw, p, s, scale):
+    rng = np.random.default_rng(12)
+    img = rng.uniform(0, 1, (*hw, 3)).astype(np.float32)
+    padded = O.add_padding(img, p, s)
+    ref_patches, pos = O.extract_patches(padded, p, s)
+    got = ctx.extract_patches(_dev(ctx, img, torch.float32), p, s, mul=2.0, add=-1.0)
+    assert got.shape == ref_patches.shape
+    assert np.array_equal(got.cpu().numpy(), ref_patches * 2.0 - 1.0)
+    # fake "HR" patches: arbitrary values, reconstruct with the reference's scatter-add semantics
+    if scale * hw[0] * scale * hw[1] > 3e6:
+        hr = np.repeat(np.repeat(ref_patches, scale, axis=1), scale, axis=2)
+    else:
+        hr = rng.uniform(-0.2, 1.2, (len(pos), p * scale, p * scale, 3)).astype(np.float32)
+    ref = O.overlap_add(hr, pos, padded.shape, hw, p, scale)
+    out = ctx.overlap_add(_dev(ctx, hr, torch.float32), hw[0], hw[1], p, s, scale).cpu().numpy()
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) <= 1e-6

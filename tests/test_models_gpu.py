@@ -1,0 +1,120 @@
+"""Model-level parity through sr_forward vs the CPU oracle graphs, seeded synthetic weights.
+
+fp32 models: rel-L2 <= 1e-5 vs the fp32 oracle run in fp64.
+bf16 models: fp32 oracle on bf16-rounded weights/inputs; activations are stored in bf16 between
+layers, so the bound is loose (rel-L2 <= 3e-2) and a PSNR floor is asserted as well.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as M
+from oracle import ops as O
+from sr355 import Model
+from sr355.weights import bf16_rounded, init_weights, round_to_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def run(ctx, model, w, x, dtype):
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    model.set_weights(w)
+    return model.forward(ctx.to_device(x, td)).float().cpu().numpy()
+
+
+def prep(w, x, dtype):
+    if dtype == "bf16":
+        return bf16_rounded(w), round_to_bf16(x)
+    return w, x
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_srcnn_forward(ctx, dtype):
+    m = Model("srcnn", compute_dtype=dtype, ctx=ctx)
+    assert m.layer_shapes() == M.srcnn_layers()
+    assert m.count_params() == 28931                      # SRCNN.ipynb:L141
+    w = init_weights(m.layer_shapes(), seed=1000)
+    x = np.random.default_rng(1).uniform(0, 1, (3, 33, 33, 3)).astype(np.float32)
+    w, x = prep(w, x, dtype)
+    ref = M.srcnn_forward(x, w, dtype=np.float64)
+    got = run(ctx, m, w, x, dtype)
+    assert rel_l2(got, ref) <= (1e-5 if dtype == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("scale,nb", [(2, 16), (4, 3), (3, 2)])
+def test_edsr_forward(ctx, scale, nb, dtype):
+    m = Model("edsr", compute_dtype=dtype, scale_factor=scale, num_blocks=nb, num_filters=64, res_scaling=0.1, ctx=ctx)
+    assert m.layer_shapes() == M.edsr_layers(scale, 3, nb, 64)
+    if scale == 2 and nb == 16:
+        assert m.count_params() == 1369859                # EDSR.ipynb:L392
+    w = init_weights(m.layer_shapes(), scheme="he_normal", seed=2000)
+    x = np.random.default_rng(2).uniform(0, 1, (2, 24, 24, 3)).astype(np.float32)
+    w, x = prep(w, x, dtype)
+    ref = M.edsr_forward(x, w, scale, nb, 0.1, dtype=np.float64)
+    got = run(ctx, m, w, x, dtype)
+    assert got.shape == ref.shape == (2, 24 * scale, 24 * scale, 3)
+    assert rel_l2(got, ref) <= (1e-5 if dtype == "f32" else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("scale,G,nb,att", [(2, 8, 4, True), (4, 32, 2, True), (4, 32, 2, False)])
+def test_esrgan_generator_forward(ctx, scale, G, nb, att, dtype):
+    m = Model("esrgan_g", compute_dtype=dtype, scale_factor=scale, num_blocks=nb, growth_channels=G, use_attention=att, ctx=ctx)
+    if att:
+        assert m.layer_shapes() == M.esrgan_g_layers(scale, G, nb)
+    if (scale, G, nb, att) == (2, 8, 4, True):
+        assert m.count_params() == 1162915                # ESRGAN.ipynb:L636
+    w = init_weights(m.layer_shapes(), seed=3000)
+    x = np.random.default_rng(3).uniform(-1, 1, (2, 24, 24, 3)).astype(np.float32)
+    w, x = prep(w, x, dtype)
+    ref = M.esrgan_g_forward(x, w, scale, nb, dtype=np.float64, attention=att)
+    got = run(ctx, m, w, x, dtype)
+    assert got.shape == ref.shape
+    err = rel_l2(got, ref)
+    assert err <= (2e-5 if dtype == "f32" else 3e-2), err
+    if dtype == "bf16":   # outputs in [-1,1] -> [0,1] PSNR against the oracle
+        assert O.psnr((got + 1) / 2, (ref + 1) / 2, dtype=np.float64).min() >= 38.0
+
+
+def test_esrgan_predict_chunking_invariant(ctx):
+    """keras predict(batch_size) chunking must not change results (no batch-coupled op)."""
+    m = Model("esrgan_g", compute_dtype="f32", scale_factor=2, num_blocks=1, growth_channels=8, ctx=ctx)
+    m.set_weights(init_weights(m.layer_shapes(), seed=3100))
+    x = np.random.default_rng(4).uniform(-1, 1, (5, 24, 24, 3)).astype(np.float32)
+    a = m.predict(x, batch_size=16)
+    b = m.predict(x, batch_size=2)
+    assert np.array_equal(a, b)
+    assert m.predict(x[:0], batch_size=16).shape == (0, 48, 48, 3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_vgg16_classifier_forward(ctx, dtype):
+    m = Model("vgg16", compute_dtype=dtype, num_classes=2, ctx=ctx)
+    assert m.layer_shapes() == M.vgg16_classifier_layers(2)
+    assert m.count_params() == 14846530                   # VGG16.ipynb:L151-153
+    w = init_weights(m.layer_shapes(), scheme="he_normal", seed=4000)
+    x = np.random.default_rng(5).uniform(0, 1, (3, 96, 96, 3)).astype(np.float32)
+    w, x = prep(w, x, dtype)
+    ref = M.vgg16_classifier_forward(x, w, dtype=np.float64)
+    got = run(ctx, m, w, x, dtype)
+    assert got.shape == (3, 2)
+    assert np.allclose(got.sum(axis=1), 1.0, atol=1e-2 if dtype == "bf16" else 1e-5)
+    assert np.max(np.abs(got - ref)) <= (1e-5 if dtype == "f32" else 3e-2)
+
+
+def test_forward_errors(ctx):
+    m = Model("srcnn", compute_dtype="f32", ctx=ctx)
+    x = ctx.to_device(np.zeros((1, 16, 16, 3), np.float32))
+    with pytest.raises(RuntimeError):      # not finalised (weights never set)
+        m.forward(x)
+    with pytest.raises(KeyError):
+        m.set_weights({})
+    with pytest.raises(ValueError):
+        Model("edsr", scale_factor=5, ctx=ctx)
