@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: 4x-SR output MPix/s on 512x512 LR tiles (configs[2]).
+
+One step = one pass of the hot path over one batch: 16 LR tiles [512,512,3] (resident in HBM) ->
+ESRGAN.super_resolve_image (reference patch mode: reflect pad, 441 LR patches 48x48 stride 24 per tile,
+RRDB generator x4 NB=23 G=32 with both SelfAttention layers, bf16 storage / fp32 accumulate, overlap
+average, crop, clip) -> PSNR/SSIM against the HR tiles -> (N>1) all-reduce of the metric sums over RCCL.
+Weak scaling: every rank owns 16 tiles.  value = SR output megapixels of all ranks / wall time (max over ranks).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "super-resolution-images-for-3d-printing-defect-detection_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+TILES_PER_GPU, LR, SCALE, NB, G, PATCH, STRIDE = 16, 512, 4, 23, 32, 48, 24
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def cpu_baseline(weights, lr_tile, budget_s=15.0):
+    """The oracle (CPU restatement, torch-CPU fp32, all host cores) on a bounded sample of the same patches."""
+    from oracle import models as OM
+    from oracle import ops as OO
+    torch.set_num_threads(os.cpu_count() or 1)
+    padded = OO.add_padding(lr_tile, PATCH, STRIDE)
+    patches, _ = OO.extract_patches(padded, PATCH, STRIDE)
+    x = patches * 2.0 - 1.0
+    t0 = time.perf_counter()
+    OM.esrgan_g_forward(x[:2], weights, SCALE, NB)
+    per_patch = (time.perf_counter() - t0) / 2
+    n = int(min(len(x) - 2, max(2, budget_s / max(per_patch, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(2, 2 + n, 2):
+        OM.esrgan_g_forward(x[i:i + 2], weights, SCALE, NB)
+    dt = time.perf_counter() - t0
+    per_tile = dt / n * len(x)
+    return {"value": (LR * SCALE) ** 2 / 1e6 / per_tile, "unit": "MPix/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} of {TILES_PER_GPU * len(x)} LR patches 48x48 (ESRGAN x4 NB=23 G=32 with attention, fp32 torch-CPU oracle), "
+                      f"{dt:.1f} s, extrapolated to a 441-patch tile"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=147, help="patches per sr_forward call")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass (no roofline object)")
+    ap.add_argument("--no-attention", action="store_true", help="non-reference graph, kernel tuning only")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from sr355 import Context
+    from sr355.synth import make_pairs
+    from sr355.weights import init_weights
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+
+    ctx = Context.get(local)
+    model = ESRGAN(compute_dtype="bf16")
+    model.setup_model(scale_factor=SCALE, growth_channels=G, num_rrdb_blocks=NB, use_attention=not args.no_attention)
+    weights = init_weights(model.generator.layer_shapes(), seed=3000)
+    model.set_weights(weights)
+
+    # synthetic 3D-print tiles, seeded per rank; 4 distinct tiles repeated to 16
+    lr4, hr4 = make_pairs(4, LR, LR, SCALE, seed=42 + 2 + 1000 * rank)
+    reps = TILES_PER_GPU // 4
+    lr = ctx.to_device(np.tile(lr4, (reps, 1, 1, 1)))
+    hr = ctx.to_device(np.tile(hr4, (reps, 1, 1, 1)))
+    sums = torch.zeros(3, dtype=torch.float64, device=ctx.torch_device)
+
+    def step():
+        sums.zero_()
+        for t in range(TILES_PER_GPU):
+            sr, _ = model.super_resolve_image(lr[t], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk)
+            sums[0] += ctx.psnr(hr[t:t + 1], sr[None])[0].double()
+            sums[1] += ctx.ssim(hr[t:t + 1], sr[None])[0].double()
+            sums[2] += 1.0
+        if world > 1:
+            dist.all_reduce(sums)          # RCCL over xGMI: the path's only exchange step
+        return sums
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # the same K steps again with a HIP-event pair around every hot-kernel launch (on the launching stream):
+    # per-kernel durations for the roofline object.  `value` comes from the un-instrumented pass above.
+    prof, elapsed_prof = [], None
+    if not args.no_profile:
+        ctx.profile_begin()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed_prof = time.perf_counter() - t1
+        prof = ctx.profile_end()
+    et = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
+    if world > 1:
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+    elapsed = float(et.item())
+    res = out.cpu().numpy()
+
+    if rank == 0:
+        mpix = world * TILES_PER_GPU * (LR * SCALE) ** 2 / 1e6
+        roof = None
+        if prof:
+            prof.sort(key=lambda r: -r["total_ms"])
+            dom = prof[0]
+            avg_ms = dom["total_ms"] / dom["launches"]
+            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
+            if os.path.isfile(tp):
+                traffic = json.load(open(tp)).get(dom["kernel"])
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                    "flop_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+                    "instrumented_ms_per_step": elapsed_prof / args.steps * 1e3}
+        line = {
+            "metric": "4x-SR MPix/s on 512x512 LR batch", "value": mpix * args.steps / elapsed, "unit": "MPix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: ESRGAN-RRDB x4 (NB=23,G=32,2xSelfAttention) on 16 LR tiles 512x512 per GPU, "
+                                   "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
+                       "tiles_per_gpu": TILES_PER_GPU, "global_batch": world * TILES_PER_GPU, "patches_per_forward": args.chunk,
+                       "parallelism": f"dp{world} (tile shards, metric all-reduce only)"},
+            "quality": {"mean_psnr_vs_hr_db": res[0] / res[2], "mean_ssim_vs_hr": res[1] / res[2], "note": "random-init weights"},
+            "roofline": roof,
+            "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
+                         "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2),
+                         "gbps": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in prof[:8]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, lr4[0])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

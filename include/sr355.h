@@ -68,6 +68,14 @@ int  sr_mem_info(sr_ctx* ctx, int64_t* current_bytes, int64_t* peak_bytes);
  * blocks until that forward has finished. */
 int  sr_last_forward_ms(sr_ctx* ctx, float* ms);
 
+/* Per-launch timing of the hot kernels with HIP events recorded on the launching stream (the
+ * reference's analogue is its time.perf_counter() bracket around predict, SRCNN_model.py:208-212).
+ * begin: start collecting; end: synchronise the device and write a JSON array
+ * [{"kernel","launches","total_ms","flops","bytes"}...] (algorithmic FLOP / HBM bytes per kernel
+ * template instance) into `json` (capacity `cap` bytes). */
+int  sr_profile_begin(sr_ctx* ctx);
+int  sr_profile_end(sr_ctx* ctx, char* json, int64_t cap);
+
 /* ---- models: replaces Keras model build + predict ------------------------------------------ */
 /* Keras graph construction: SRCNN_model.py:45-53, EDSR_model.py:96-125, ESRGAN_model.py:303-345,
  * VGG16_model.py:57-97. */

@@ -1,0 +1,102 @@
+"""ESRGAN generator on MI355X behind the reference's class surface
+(reference: deep_learning_models/ESRGAN_model.py).
+
+Generator (ESRGAN_model.py:303-345): conv3->64, NB x RRDB (3 dense blocks of 5 convs, residual scale 0.2),
+trunk conv + skip, SelfAttention, log2(scale) x (conv64->256, depth_to_space, LeakyReLU 0.2,
+SelfAttention after the first), conv64 ReLU, conv->3 tanh.  The discriminator, VGG19 perceptual net and
+the GAN training loop (_train_step :475-533) are the next row and are not built here.
+"""
+import os
+
+import numpy as np
+import torch
+
+from sr355 import pipeline as P
+from sr355.wrappers import DeviceModelMixin, load_pretrained
+
+
+class ESRGAN(DeviceModelMixin):
+    def __init__(self, compute_dtype="bf16"):
+        self.generator = None
+        self.discriminator = None
+        self.vgg_model = None
+        self.g_optimizer = None
+        self.d_optimizer = None
+        self.trained = False
+        self.compute_dtype = compute_dtype
+
+    def _mark_trained(self, v):
+        self.trained = v
+
+    def setup_model(self, scale_factor=2, growth_channels=32, num_rrdb_blocks=23, input_shape=(None, None, 3),
+                    output_shape=(None, None, 3), from_trained=False, generator_pretrained_path=None,
+                    discriminator_pretrained_path=None, use_attention=True):
+        self.scale_factor = scale_factor
+        weights = None
+        if from_trained:
+            if generator_pretrained_path is None or not os.path.exists(generator_pretrained_path):
+                raise FileNotFoundError(f"Generator pretrained path does not exist: {generator_pretrained_path}")
+            weights = load_pretrained(generator_pretrained_path)
+            growth_channels = int(weights["rrdb_0_dense1_conv1"][0].shape[-1]) if "rrdb_0_dense1_conv1" in weights else growth_channels
+            num_rrdb_blocks = len({n.split("_")[1] for n in weights if n.startswith("rrdb_")})
+        self.generator = self._make("esrgan_g", self.compute_dtype, scale_factor=scale_factor, channels=int(input_shape[-1]),
+                                    num_blocks=num_rrdb_blocks, growth_channels=growth_channels, use_attention=use_attention)
+        if weights is not None:
+            self.set_weights(weights)
+            print(f"- Generator loaded from: {generator_pretrained_path}")
+        else:
+            self._random_init(seed=3000)
+
+    def fit(self, *args, **kwargs):
+        raise NotImplementedError("ESRGAN adversarial training is the next row (SURVEY.md 8f-1), not built yet")
+
+    def generate(self, lr_batch):
+        """generator(lr, training=False) on a [-1,1] batch (ESRGAN_model.py:810); NumPy or device tensor."""
+        if self.generator is None:
+            raise RuntimeError("Generator is not initialized.")
+        return self.generator.predict(lr_batch, batch_size=64)
+
+    def evaluate(self, test_dataset):
+        """PSNR/SSIM part of ESRGAN.evaluate (ESRGAN_model.py:782-856): iterable of ([-1,1] LR batch, [-1,1] HR batch);
+        mean of per-batch means (the reference's weighting, last partial batch included).  avg_g_loss needs the
+        discriminator/VGG19 losses of the training row and is reported as None."""
+        if not self.trained:
+            raise RuntimeError("Model has not been trained.")
+        tp = ts = 0.0
+        nb = 0
+        for lr_batch, hr_batch in test_dataset:
+            gen = self.ctx.to_device(self.generate(np.asarray(lr_batch, np.float32)))
+            real = self.ctx.to_device(np.asarray(hr_batch, np.float32))
+            g01, r01 = (gen + 1.0) / 2.0, (real + 1.0) / 2.0
+            tp += float(self.ctx.psnr(r01, g01).mean().item())
+            ts += float(self.ctx.ssim(r01, g01).mean().item())
+            nb += 1
+        metrics = {"avg_psnr": tp / nb, "avg_ssim": ts / nb, "avg_g_loss": None}
+        print("Evaluation Results:")
+        print(f"  Average PSNR: {metrics['avg_psnr']:.4f}")
+        print(f"  Average SSIM: {metrics['avg_ssim']:.4f}")
+        return metrics
+
+    def super_resolve_image(self, lr_img, patch_size_lr=48, stride=24, batch_size=16):
+        """Reflect-pad, cut LR patches, [0,1]->[-1,1], generator, (out+1)/2, overlap-average, crop, clip
+        (ESRGAN_model.py:858-979).  `batch_size` is Keras' predict chunk; chunking does not change results, so the
+        device chunk is max(batch_size, 147) patches."""
+        if not self.trained:
+            raise RuntimeError("Model has not been trained or loaded.")
+        if self.generator is None:
+            raise RuntimeError("Generator is not initialized.")
+        if not hasattr(self, "scale_factor") or self.scale_factor is None:
+            raise ValueError("scale_factor is not set. Ensure setup_model was called.")
+        lr, is_np = P.as_device_image(self.ctx, lr_img)
+        sr, metrics = P.patchwise_sr(self.generator, lr, patch_size_lr, stride, self.scale_factor, chunk=max(int(batch_size), 147),
+                                     in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5)
+        return (sr.cpu().numpy() if is_np else sr), metrics
+
+    def save(self, directory, timestamp):
+        if not self.trained:
+            raise RuntimeError("Cannot save an untrained model.")
+        os.makedirs(directory, exist_ok=True)
+        generator_path = os.path.join(directory, f"ESRGAN_generator_x{self.scale_factor}_{timestamp}.npz")
+        self._save_npz(generator_path)
+        print(f"Generator model saved to {generator_path}")
+        return generator_path

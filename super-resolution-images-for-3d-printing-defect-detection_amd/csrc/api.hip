@@ -10,6 +10,7 @@
 //   * SelfAttention = one 1x1 conv producing f|g|h side by side, the streaming-softmax kernel, and
 //     the 1x1 "v" conv with the residual add in its epilogue.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <memory>
@@ -45,6 +46,24 @@ void* sr_ctx::scratch(size_t bytes) {
     scratch_buf = dalloc(cap);
     if (scratch_buf) scratch_cap = cap;
     return scratch_buf;
+}
+
+int sr_ctx::prof_open(const std::string& name, double flops, double bytes, hipStream_t st) {
+    if (!prof) return -1;
+    int ni = -1;
+    for (size_t i = 0; i < prof_names.size(); ++i) if (prof_names[i] == name) { ni = (int)i; break; }
+    if (ni < 0) { prof_names.push_back(name); ni = (int)prof_names.size() - 1; }
+    hipEvent_t e[2];
+    for (int k = 0; k < 2; ++k) {
+        if (!ev_pool.empty()) { e[k] = ev_pool.back(); ev_pool.pop_back(); }
+        else if (hipEventCreate(&e[k]) != hipSuccess) return -1;
+    }
+    (void)hipEventRecord(e[0], st);
+    prof_recs.push_back(ProfRec{ni, e[0], e[1], flops, bytes});
+    return (int)prof_recs.size() - 1;
+}
+void sr_ctx::prof_close(int rec, hipStream_t st) {
+    if (rec >= 0) (void)hipEventRecord(prof_recs[rec].e1, st);
 }
 
 // =================================================================================================
@@ -84,13 +103,13 @@ struct sr_model {
     std::vector<Op> ops;
     int in_C = 3, out_C = 3, out_mul = 1; bool out_vec = false;
     bool finalized = false;
-    int aB = 0, aH = 0, aW = 0;       // dims the workspaces are currently sized for
+    std::vector<size_t> bufcap;       // bytes currently allocated per workspace buffer (grow-only)
 
     int find_param(const std::string& n, int which) const {
         for (size_t i = 0; i < params.size(); ++i) if (params[i].which == which && params[i].name == n) return (int)i;
         return -1;
     }
-    void free_bufs() { for (auto& p : bufp) { if (p) ctx->dfree(p); p = nullptr; } aB = aH = aW = 0; }
+    void free_bufs() { for (auto& p : bufp) { if (p) ctx->dfree(p); p = nullptr; } bufcap.assign(bufcap.size(), 0); }
 };
 
 namespace {
@@ -271,21 +290,23 @@ int build_vgg16(sr_model* m) {
 
 inline void buf_hw(const BufSpec& b, int H, int W, int* h, int* w) { *h = (H * b.mul) >> b.shift; *w = (W * b.mul) >> b.shift; }
 
+// Workspaces grow on demand and are never shrunk.  Every buffer is [pixels][Cbuf]: the position of the pad
+// channels inside a pixel does not depend on (B,H,W), so zeroing them once at allocation stays valid for every
+// later shape (no kernel ever writes a pad channel).
 int ensure_workspace(sr_model* m, int B, int H, int W) {
-    if (m->aB == B && m->aH == H && m->aW == W) return SR_OK;
-    m->free_bufs();
-    m->bufp.assign(m->bufs.size(), nullptr);
+    if (m->bufp.size() != m->bufs.size()) { m->bufp.assign(m->bufs.size(), nullptr); m->bufcap.assign(m->bufs.size(), 0); }
     for (size_t i = 0; i < m->bufs.size(); ++i) {
         const BufSpec& b = m->bufs[i];
         size_t bytes;
         if (b.vec) bytes = (size_t)B * b.C * sizeof(float);
         else { int h, w; buf_hw(b, H, W, &h, &w); bytes = (size_t)B * h * w * b.Cbuf * dtype_size(m->T) + 4096; }
+        if (bytes <= m->bufcap[i]) continue;
+        if (m->bufp[i]) { SR_HIP(m->ctx, hipDeviceSynchronize()); m->ctx->dfree(m->bufp[i]); m->bufp[i] = nullptr; m->bufcap[i] = 0; }
         m->bufp[i] = m->ctx->dalloc(bytes);
-        if (!m->bufp[i]) { m->free_bufs(); return SR_ERR_OOM; }
-        // pad channels must read as zero: they meet zero weights, but 0*NaN would still poison a sum
+        if (!m->bufp[i]) return SR_ERR_OOM;
         SR_HIP(m->ctx, hipMemset(m->bufp[i], 0, bytes));
+        m->bufcap[i] = bytes;
     }
-    m->aB = B; m->aH = H; m->aW = W;
     return SR_OK;
 }
 
@@ -317,6 +338,8 @@ void sr_destroy(sr_ctx* ctx) {
     for (void* p : ps) ctx->dfree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto& e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -334,6 +357,44 @@ int sr_last_forward_ms(sr_ctx* ctx, float* ms) {
     if (!ctx->timed) return ctx->fail(SR_ERR_STATE, "no forward has run on this ctx");
     SR_HIP(ctx, hipEventSynchronize(ctx->ev1));
     SR_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return SR_OK;
+}
+
+int sr_profile_begin(sr_ctx* ctx) {
+    if (!ctx) return SR_ERR_INVALID;
+    for (auto& r : ctx->prof_recs) { ctx->ev_pool.push_back(r.e0); ctx->ev_pool.push_back(r.e1); }
+    ctx->prof_recs.clear();
+    ctx->prof = true;
+    return SR_OK;
+}
+
+int sr_profile_end(sr_ctx* ctx, char* json, int64_t cap) {
+    if (!ctx || !json || cap <= 0) return SR_ERR_INVALID;
+    ctx->prof = false;
+    SR_HIP(ctx, hipDeviceSynchronize());
+    struct Agg { int64_t n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::vector<Agg> agg(ctx->prof_names.size());
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        Agg& a = agg[r.name];
+        a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    }
+    std::string s = "[";
+    bool first = true;
+    for (size_t i = 0; i < agg.size(); ++i) {
+        if (!agg[i].n) continue;
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s{\"kernel\": \"%s\", \"launches\": %lld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", ctx->prof_names[i].c_str(), (long long)agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
+        s += buf;
+        first = false;
+    }
+    s += "]";
+    for (auto& r : ctx->prof_recs) { ctx->ev_pool.push_back(r.e0); ctx->ev_pool.push_back(r.e1); }
+    ctx->prof_recs.clear();
+    if ((int64_t)s.size() + 1 > cap) return ctx->fail(SR_ERR_CAPACITY, "profile buffer too small");
+    memcpy(json, s.c_str(), s.size() + 1);
     return SR_OK;
 }
 

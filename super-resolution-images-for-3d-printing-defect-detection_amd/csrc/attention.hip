@@ -176,9 +176,12 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
         return ctx->fail(SR_ERR_INVALID, "attention: views must be 16-byte aligned");
     AttnParams p{static_cast<const char*>(qkv), cs, qoff, koff, voff, static_cast<char*>(o), o_cs, o_coff, N};
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)B);
+    if (dtype != SR_DTYPE_BF16 && dtype != SR_DTYPE_F32) return ctx->fail(SR_ERR_INVALID, "attention: dtype must be f32 or bf16");
+    const int rec = ctx->prof_open(dtype == SR_DTYPE_BF16 ? "attn<bf16>" : "attn<f32>", 2.0 * B * (double)N * N * 40.0,
+                                   (double)B * N * 80.0 * esz, st);
     if (dtype == SR_DTYPE_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(256), 0, st, p);
-    else if (dtype == SR_DTYPE_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, st, p);
-    else return ctx->fail(SR_ERR_INVALID, "attention: dtype must be f32 or bf16");
+    else hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, st, p);
+    ctx->prof_close(rec, st);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }

@@ -28,6 +28,16 @@ struct sr_ctx {
     void* scratch_buf = nullptr;
     size_t scratch_cap = 0;
 
+    // per-launch HIP-event timing of the hot kernels (sr_profile_begin/_end)
+    struct ProfRec { int name; hipEvent_t e0, e1; double flops, bytes; };
+    bool prof = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> ev_pool;
+    // returns record index or -1 (profiling off); e0 is recorded on `st` before the launch
+    int prof_open(const std::string& name, double flops, double bytes, hipStream_t st);
+    void prof_close(int rec, hipStream_t st);
+
     void* dalloc(size_t bytes);   // nullptr on failure (err set)
     void dfree(void* p);
     void* scratch(size_t bytes);  // reduction scratch; stream-ordered reuse (one stream per ctx at a time)
@@ -55,7 +65,8 @@ struct ConvWeights {          // device-resident, MFMA-fragment-ordered (see con
     int CinP = 0, CoutP = 0;  // padded sizes the kernel iterates over
     int thin = 0;             // 1: Cin fits one 16-byte slice per pixel (taps paired in a k-group)
     int KGPT = 2;             // wide: k-groups per tap per stage (2 -> 64 B of channels, 4 -> 128 B)
-    int NT = 1;               // 32-wide cout blocks per workgroup
+    int NT = 1;               // 32-wide cout blocks per workgroup (rows variant: 16-wide blocks, NB16)
+    int rows = 0;             // 1: bf16 3x3 row-sliding kernel (conv_rows.hip) and its weight layout
     int nchunks = 1;          // wide: Cin stages;  thin: unused
     size_t bytes = 0;
 };

@@ -26,11 +26,15 @@
 //
 // HBM traffic per launch (algorithmic): B*H*W*(Cin + Cout)*sizeof(T) (+ skips); FLOP
 // 2*B*H*W*KS^2*Cin*Cout.  DESIGN.md prices each layer against both roofs.
-#include "common.h"
+#include "conv_common.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
+
+using namespace convk;
 
 template <typename T> struct TT;
 template <> struct TT<bf16_t> { static constexpr int E = 8; typedef bf16x8 frag; };
@@ -45,112 +49,21 @@ __device__ __forceinline__ f32x16 mma(f32x4 a, f32x4 b, f32x16 c) {
     return c;
 }
 
-struct ConvParams {
-    const char* in; int64_t in_cs; int in_coff;
-    const char* w; const float* bias;
-    char* out; int64_t out_cs; int out_coff; int out_f32;
-    const char* s1; int64_t s1_cs; int s1_coff; float beta1;
-    const char* s2; int64_t s2_cs; int s2_coff; float beta2;
-    float alpha; int act; int clip; int r; int Cd;
-    int B, H, W, Cout;
-    int nchunks;        // wide: Cin chunks; thin: number of k-groups (taps pairs)
-    int tilesX, tilesY;
-    int vec;            // epilogue may use 4-element vector loads/stores
-};
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-        case SR_ACT_RELU: return fmaxf(v, 0.f);
-        case SR_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
-        case SR_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
-}
-
-template <typename T> __device__ __forceinline__ void load4(const char* base, int64_t eoff, bool vec, int n, float v[4]);
-template <> __device__ __forceinline__ void load4<float>(const char* base, int64_t eoff, bool vec, int n, float v[4]) {
-    const float* p = reinterpret_cast<const float*>(base) + eoff;
-    if (vec) { f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
-    else { for (int e = 0; e < 4; ++e) v[e] = e < n ? p[e] : 0.f; }
-}
-template <> __device__ __forceinline__ void load4<bf16_t>(const char* base, int64_t eoff, bool vec, int n, float v[4]) {
-    const bf16_t* p = reinterpret_cast<const bf16_t*>(base) + eoff;
-    if (vec) { bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) v[e] = (float)t[e]; }
-    else { for (int e = 0; e < 4; ++e) v[e] = e < n ? (float)p[e] : 0.f; }
-}
-template <typename T> __device__ __forceinline__ void store4(char* base, int64_t eoff, bool vec, int n, const float v[4], bool f32);
-template <> __device__ __forceinline__ void store4<float>(char* base, int64_t eoff, bool vec, int n, const float v[4], bool) {
-    float* p = reinterpret_cast<float*>(base) + eoff;
-    if (vec) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
-    else { for (int e = 0; e < n; ++e) p[e] = v[e]; }
-}
-template <> __device__ __forceinline__ void store4<bf16_t>(char* base, int64_t eoff, bool vec, int n, const float v[4], bool f32) {
-    if (f32) { store4<float>(base, eoff, vec, n, v, true); return; }
-    bf16_t* p = reinterpret_cast<bf16_t*>(base) + eoff;
-    if (vec) { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *reinterpret_cast<bf16x4*>(p) = t; }
-    else { for (int e = 0; e < n; ++e) p[e] = (bf16_t)v[e]; }
-}
-
-// Epilogue shared by both kernels: bias, activation, alpha, two scaled skips, clip, (shuffled) store.
+// Epilogue of the 32x32 kernels: lane (r,h) owns pixel r of each M-block and couts 8q+4h..+3.
 template <typename T, int NT, int MT>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][NT], int b, int y0, int x0, int ct,
                                               int wave, int r, int h) {
-    const bool vec = p.vec != 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int oy = y0 + (wave * MT + m) * 2 + (r >> 4);
         const int ox = x0 + (r & 15);
         if (oy >= p.H || ox >= p.W) continue;
-        const int64_t pix = ((int64_t)b * p.H + oy) * p.W + ox;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c0 = (ct * NT + n) * 32 + 8 * q + 4 * h;
-                if (c0 >= p.Cout) continue;
-                const int nv = min(4, p.Cout - c0);
-                const bool v4 = vec && nv == 4;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[m][n][4 * q + e] + p.bias[c0 + e];
-                    v[e] = act_apply(t, p.act) * p.alpha;
-                }
-                if (p.s1) {
-                    float s[4];
-                    load4<T>(p.s1, pix * p.s1_cs + p.s1_coff + c0, v4, nv, s);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.beta1 * s[e];
-                }
-                if (p.s2) {
-                    float s[4];
-                    load4<T>(p.s2, pix * p.s2_cs + p.s2_coff + c0, v4, nv, s);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.beta2 * s[e];
-                }
-                if (p.clip) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
-                }
-                int64_t dst;
-                if (p.r <= 1) {
-                    dst = pix * p.out_cs + p.out_coff + c0;
-                    store4<T>(p.out, dst, v4, nv, v, p.out_f32 != 0);
-                } else if (v4) {   // Cd % 4 == 0 guaranteed by host when vec
-                    const int sub = c0 / p.Cd, c = c0 - sub * p.Cd;
-                    const int i = sub / p.r, j = sub - i * p.r;
-                    dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs +
-                          p.out_coff + c;
-                    store4<T>(p.out, dst, true, 4, v, p.out_f32 != 0);
-                } else {
-                    for (int e = 0; e < nv; ++e) {   // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c
-                        const int co = c0 + e, sub = co / p.Cd, c = co - sub * p.Cd;
-                        const int i = sub / p.r, j = sub - i * p.r;
-                        dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs +
-                              p.out_coff + c;
-                        store4<T>(p.out, dst, false, 1, v + e, p.out_f32 != 0);
-                    }
-                }
+                const float a[4] = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+                epilogue4<T>(p, b, oy, ox, (ct * NT + n) * 32 + 8 * q + 4 * h, a);
             }
         }
     }
@@ -435,6 +348,8 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
     if (KS == 5 && !(Cin <= E)) w.NT = 1;   // 25 taps of weights: keep the LDS stage small
     const int nct = nb / w.NT, ntap = KS * KS;
     w.thin = Cin <= E;
+    static const bool force_v1 = getenv("SR355_CONV_V1") != nullptr;
+    w.rows = (dtype == SR_DTYPE_BF16 && KS == 3 && !w.thin && !force_v1) ? 1 : 0;
     if (!w.thin && KS == 9) return ctx->fail(SR_ERR_INVALID, "conv: 9x9 supported for <= one 16-byte channel slice only");
     std::vector<char> host;
     auto put = [&](size_t idx, float v) {
@@ -445,7 +360,24 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
         if (tap >= ntap || ci >= Cin || co >= Cout) return 0.f;
         return hwio[((size_t)tap * Cin + ci) * Cout + co];
     };
-    if (w.thin) {
+    if (w.rows) {
+        w.CoutP = round_up(Cout, 16);
+        const int nb16 = w.CoutP / 16;
+        w.NT = (nb16 % 4 == 0) ? 4 : (nb16 % 2 == 0 ? 2 : 1);
+        const int nct16 = nb16 / w.NT;
+        w.KGPT = 1;
+        w.CinP = round_up(Cin, 32);
+        w.nchunks = w.CinP / 32;
+        host.assign((size_t)nct16 * w.nchunks * 9 * w.NT * 1024, 0);
+        size_t idx = 0;
+        for (int ct = 0; ct < nct16; ++ct)
+            for (int ch = 0; ch < w.nchunks; ++ch)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int n = 0; n < w.NT; ++n)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j, ++idx)
+                                put(idx, W(tap, ch * 32 + (lane >> 4) * 8 + j, (ct * w.NT + n) * 16 + (lane & 15)));
+    } else if (w.thin) {
         w.CinP = E; w.KGPT = 0;
         const int KGT = (ntap + 1) / 2;
         w.nchunks = KGT;
@@ -517,6 +449,19 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     if (p.s2) vec = vec && (p.s2_cs % 4 == 0) && (p.s2_coff % 4 == 0) && ((uintptr_t)p.s2 % (4 * esz) == 0);
     p.vec = vec ? 1 : 0;
     const int nct = w.CoutP / 32 / w.NT;
-    if (w.dtype == SR_DTYPE_BF16) return dispatch<bf16_t>(ctx, w, p, nct, st);
-    return dispatch<float>(ctx, w, p, nct, st);
+    int rec = -1;
+    if (ctx->prof) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.rows ? "rows" : (w.thin ? "thin" : "wide"),
+                 w.dtype == SR_DTYPE_BF16 ? "bf16" : "f32", w.KS, w.KGPT, w.NT);
+        const double px = (double)B * H * W;
+        double bytes = px * ((double)w.Cin * esz + (double)w.Cout * osz);
+        if (p.s1) bytes += px * w.Cout * esz;
+        if (p.s2) bytes += px * w.Cout * esz;
+        rec = ctx->prof_open(nm, 2.0 * px * w.KS * w.KS * w.Cin * w.Cout, bytes, st);
+    }
+    const int rc = w.rows ? conv_rows_launch(ctx, w, p, st)
+                          : ((w.dtype == SR_DTYPE_BF16) ? dispatch<bf16_t>(ctx, w, p, nct, st) : dispatch<float>(ctx, w, p, nct, st));
+    ctx->prof_close(rec, st);
+    return rc;
 }

@@ -1,0 +1,102 @@
+// conv_common.h -- pieces shared by the conv kernels: launch parameters and the fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace convk {
+
+struct ConvParams {
+    const char* in; int64_t in_cs; int in_coff;
+    const char* w; const float* bias;
+    char* out; int64_t out_cs; int out_coff; int out_f32;
+    const char* s1; int64_t s1_cs; int s1_coff; float beta1;
+    const char* s2; int64_t s2_cs; int s2_coff; float beta2;
+    float alpha; int act; int clip; int r; int Cd;
+    int B, H, W, Cout;
+    int nchunks;        // wide: Cin chunks; thin: number of k-groups (taps pairs)
+    int tilesX, tilesY;
+    int vec;            // epilogue may use 4-element vector loads/stores
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case SR_ACT_RELU: return fmaxf(v, 0.f);
+        case SR_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+        case SR_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+template <typename T> __device__ __forceinline__ void load4(const char* base, int64_t eoff, bool vec, int n, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const char* base, int64_t eoff, bool vec, int n, float v[4]) {
+    const float* p = reinterpret_cast<const float*>(base) + eoff;
+    if (vec) { f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    else { for (int e = 0; e < 4; ++e) v[e] = e < n ? p[e] : 0.f; }
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const char* base, int64_t eoff, bool vec, int n, float v[4]) {
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(base) + eoff;
+    if (vec) { bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int e = 0; e < 4; ++e) v[e] = (float)t[e]; }
+    else { for (int e = 0; e < 4; ++e) v[e] = e < n ? (float)p[e] : 0.f; }
+}
+template <typename T> __device__ __forceinline__ void store4(char* base, int64_t eoff, bool vec, int n, const float v[4], bool f32);
+template <> __device__ __forceinline__ void store4<float>(char* base, int64_t eoff, bool vec, int n, const float v[4], bool) {
+    float* p = reinterpret_cast<float*>(base) + eoff;
+    if (vec) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+    else { for (int e = 0; e < n; ++e) p[e] = v[e]; }
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(char* base, int64_t eoff, bool vec, int n, const float v[4], bool f32) {
+    if (f32) { store4<float>(base, eoff, vec, n, v, true); return; }
+    bf16_t* p = reinterpret_cast<bf16_t*>(base) + eoff;
+    if (vec) { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *reinterpret_cast<bf16x4*>(p) = t; }
+    else { for (int e = 0; e < n; ++e) p[e] = (bf16_t)v[e]; }
+}
+
+
+// Fused epilogue for one output pixel (b, oy, ox) and the 4 consecutive output channels starting at c0:
+// bias, activation, alpha, two scaled skips, clip[0,1], then an NHWC store or a depth_to_space (TF "DCR") store.
+template <typename T>
+__device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, int ox, int c0, const float a[4]) {
+    if (c0 >= p.Cout) return;
+    const bool vec = p.vec != 0;
+    const int64_t pix = ((int64_t)b * p.H + oy) * p.W + ox;
+    const int nv = min(4, p.Cout - c0);
+    const bool v4 = vec && nv == 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(a[e] + p.bias[c0 + e], p.act) * p.alpha;
+    if (p.s1) {
+        float s[4];
+        load4<T>(p.s1, pix * p.s1_cs + p.s1_coff + c0, v4, nv, s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p.beta1 * s[e];
+    }
+    if (p.s2) {
+        float s[4];
+        load4<T>(p.s2, pix * p.s2_cs + p.s2_coff + c0, v4, nv, s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p.beta2 * s[e];
+    }
+    if (p.clip) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+    }
+    if (p.r <= 1) {
+        store4<T>(p.out, pix * p.out_cs + p.out_coff + c0, v4, nv, v, p.out_f32 != 0);
+    } else if (v4) {   // Cd % 4 == 0 guaranteed by the host when vec
+        const int sub = c0 / p.Cd, c = c0 - sub * p.Cd;
+        const int i = sub / p.r, j = sub - i * p.r;
+        const int64_t dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs + p.out_coff + c;
+        store4<T>(p.out, dst, true, 4, v, p.out_f32 != 0);
+    } else {
+        for (int e = 0; e < nv; ++e) {   // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c
+            const int co = c0 + e, sub = co / p.Cd, c = co - sub * p.Cd;
+            const int i = sub / p.r, j = sub - i * p.r;
+            const int64_t dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs + p.out_coff + c;
+            store4<T>(p.out, dst, false, 1, v + e, p.out_f32 != 0);
+        }
+    }
+}
+
+}  // namespace convk
+
+// bf16 3x3 "row-sliding" kernel (conv_rows.hip)
+int conv_rows_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams& p, hipStream_t st);

@@ -1,0 +1,261 @@
+// conv_rows.hip -- bf16 3x3 SAME convolution, "row-sliding" implicit GEMM on v_mfma_f32_16x16x32_bf16.
+//
+// This is the kernel the ESRGAN/EDSR/VGG trunks spend their time in.  The first-generation kernel
+// (conv.hip) reads one pixel fragment from LDS per MFMA when Cout = 32, which makes the LDS -- not the
+// matrix cores -- the bound.  Here every pixel fragment is used by all three ky taps:
+//
+//   wave  = a strip of R output rows x 16 columns; workgroup = 4 waves stacked vertically (4R x 16);
+//   MFMA  = 16 couts x 16 pixels x 32 channels; A = weight fragment, B = pixel fragment, so a lane
+//           owns one pixel column and 4 consecutive couts (8-byte NHWC stores);
+//   loop  = for each 32-channel chunk, for kx in 0..2: hold the 3 (ky) x NB16 weight fragments in
+//           registers, walk the R+2 input rows of the strip once; the fragment of input row yi feeds
+//           output rows yi, yi-1, yi-2 (ky = 0, 1, 2).
+//   LDS reads per 16-cycle MFMA: (R+2)/(3*R*NB16) pixel + 1/R weight fragments (0.39 at R=6, Cout=32;
+//   the old kernel: 1.33 per 32-cycle MFMA).
+//
+// LDS image of the input halo tile: pixel-major, 64 B per pixel per chunk, no padding; 16-byte slice q
+// of pixel index t (t = row*18 + col) sits at t*64 + ((q*16) ^ ((t & 4) << 3)).  With that XOR the 16
+// lanes a ds_read_b128 services together hit 16 distinct 16-byte bank slots for every tap offset
+// (checked exhaustively over all shifts), and a staging wave still writes 1 KiB contiguously.
+// Weights are host-packed lane-linear per (chunk, tap, cout-block-of-16): a straight copy, conflict free.
+#include "conv_common.h"
+
+namespace {
+
+using namespace convk;
+
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int NB16, int R>
+__global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
+    constexpr int TH = 4 * R, TW = 16, PH = TH + 2, PW = TW + 2;
+    constexpr int NPIX = PH * PW;
+    constexpr int NIN = NPIX * 4;                 // 16-byte units per chunk
+    constexpr int NINT = (NIN + 255) / 256;
+    constexpr int LIN_BYTES = NPIX * 64;
+    constexpr int WUNITS = 9 * NB16 * 64;         // 16-byte units of weights per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lin = smem;
+    char* lw = smem + LIN_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, px = lane & 15, q = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % p.tilesX; t /= p.tilesX;
+    const int ty = t % p.tilesY;
+    const int b = t / p.tilesY;
+    const int ct = blockIdx.y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const bf16_t* inb = reinterpret_cast<const bf16_t*>(p.in) + (int64_t)b * p.H * p.W * p.in_cs + p.in_coff;
+
+    int soff[NINT], doff[NINT];
+#pragma unroll
+    for (int i = 0; i < NINT; ++i) {
+        const int u = tid + 256 * i;
+        const int pix = u >> 2, sl = u & 3;
+        const int py = pix / PW, pxx = pix - py * PW;
+        const int gy = y0 + py - 1, gx = x0 + pxx - 1;
+        const bool live = u < NIN;
+        const bool inside = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        doff[i] = live ? pix * 64 + ((sl * 16) ^ ((pix & 4) << 3)) : -1;
+        soff[i] = inside ? (int)(((int64_t)gy * p.W + gx) * p.in_cs) + sl * 8 : -1;
+    }
+    constexpr int NWT = (WUNITS + 255) / 256;     // weight units per thread
+    constexpr bool WPRE = NB16 <= 2;              // prefetch next chunk's weights into registers when they fit
+    bf16x8 pre[NINT];
+    f32x4 wpre[NWT];
+    const char* wbase = p.w + (int64_t)ct * p.nchunks * (int64_t)(WUNITS * 16);
+    auto issue = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NINT; ++i) {
+            const int so = soff[i];
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (so >= 0 ? so + chunk * 32 : 0));
+            bf16x8 z = {};
+            pre[i] = so >= 0 ? v : z;
+        }
+    };
+    auto issue_w = [&](int chunk) {
+        const char* wsrc = wbase + (int64_t)chunk * (WUNITS * 16);
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int u = tid + 256 * i;
+            wpre[i] = *reinterpret_cast<const f32x4*>(wsrc + (u < WUNITS ? u : 0) * 16);
+        }
+    };
+    auto write_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int u = tid + 256 * i;
+            if (u < WUNITS) *reinterpret_cast<f32x4*>(lw + u * 16) = wpre[i];
+        }
+    };
+
+    f32x4 acc[R][NB16];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < NB16; ++n) acc[r][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS byte address of the pixel fragment for (input row yi, kx): tt = tbase + yi*PW + kx
+    const int tbase = wave * R * PW + px;
+    auto xaddr = [&](int yi, int kx) {
+        const int tt = tbase + yi * PW + kx;
+        return tt * 64 + ((q * 16) ^ ((tt & 4) << 3));
+    };
+
+    // this lane's 4 biases per cout block, fetched before the main loop so the epilogue never waits on them
+    f32x4 biasv[NB16];
+#pragma unroll
+    for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(p.bias + (ct * NB16 + n) * 16 + 4 * q);
+
+    issue(0);
+    if (WPRE) issue_w(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NINT; ++i)
+            if (doff[i] >= 0) *reinterpret_cast<bf16x8*>(lin + doff[i]) = pre[i];
+        if (!WPRE) issue_w(chunk);     // all loads in flight together, one exposed latency per chunk
+        write_w();
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) {
+            issue(chunk + 1);
+            if (WPRE) issue_w(chunk + 1);
+        }
+        // software pipeline over (kx, yi): the fragment of the next input row is requested before this row's MFMAs
+        bf16x8 xcur = *reinterpret_cast<const bf16x8*>(lin + xaddr(0, 0));
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            bf16x8 wf[3][NB16];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int n = 0; n < NB16; ++n)
+                    wf[ky][n] = *reinterpret_cast<const bf16x8*>(lw + ((ky * 3 + kx) * NB16 + n) * 1024 + lane * 16);
+#pragma unroll
+            for (int yi = 0; yi < R + 2; ++yi) {
+                const bf16x8 xf = xcur;
+                if (yi + 1 < R + 2) xcur = *reinterpret_cast<const bf16x8*>(lin + xaddr(yi + 1, kx));
+                else if (kx + 1 < 3) xcur = *reinterpret_cast<const bf16x8*>(lin + xaddr(0, kx + 1));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yo = yi - ky;
+                    if (yo >= 0 && yo < R) {
+#pragma unroll
+                        for (int n = 0; n < NB16; ++n) acc[yo][n] = mma16(wf[ky][n], xf, acc[yo][n]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue.  lane (px, q): pixel column px, couts 4q..4q+3 of each 16-block.
+    const int ox = x0 + px;
+    const bool fast = p.vec != 0 && (p.Cout & 3) == 0;
+    if (!fast) {   // odd channel counts / unaligned views: generic per-element path (final RGB conv)
+        if (ox < p.W) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int oy = y0 + wave * R + r;
+                if (oy >= p.H) continue;
+#pragma unroll
+                for (int n = 0; n < NB16; ++n) {
+                    const float a[4] = {acc[r][n][0], acc[r][n][1], acc[r][n][2], acc[r][n][3]};
+                    epilogue4<bf16_t>(p, b, oy, ox, (ct * NB16 + n) * 16 + 4 * q, a);
+                }
+            }
+        }
+        return;
+    }
+    // fast path: 4-channel vectors everywhere; skips are loaded for a group of rows before any of them is used
+    constexpr int RG = NB16 == 4 ? 3 : R;
+    const bool has1 = p.s1 != nullptr, has2 = p.s2 != nullptr;
+    const bf16_t* s1p = reinterpret_cast<const bf16_t*>(p.s1);
+    const bf16_t* s2p = reinterpret_cast<const bf16_t*>(p.s2);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += RG) {
+        bf16x4 k1[RG][NB16], k2[RG][NB16];
+        if (has1 || has2) {
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+                const int oy = y0 + wave * R + r0 + rr;
+                const bool ok = oy < p.H && ox < p.W;
+                const int64_t pix = ok ? ((int64_t)b * p.H + oy) * p.W + ox : (int64_t)b * p.H * p.W;
+#pragma unroll
+                for (int n = 0; n < NB16; ++n) {
+                    const int c0 = min((ct * NB16 + n) * 16 + 4 * q, p.Cout - 4);
+                    if (has1) k1[rr][n] = *reinterpret_cast<const bf16x4*>(s1p + pix * p.s1_cs + p.s1_coff + c0);
+                    if (has2) k2[rr][n] = *reinterpret_cast<const bf16x4*>(s2p + pix * p.s2_cs + p.s2_coff + c0);
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const int oy = y0 + wave * R + r0 + rr;
+            if (oy >= p.H || ox >= p.W) continue;
+            const int64_t pix = ((int64_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+            for (int n = 0; n < NB16; ++n) {
+                const int c0 = (ct * NB16 + n) * 16 + 4 * q;
+                if (c0 >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[r0 + rr][n][e] + biasv[n][e], p.act) * p.alpha;
+                if (has1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.beta1 * (float)k1[rr][n][e];
+                }
+                if (has2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.beta2 * (float)k2[rr][n][e];
+                }
+                if (p.clip) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+                }
+                int64_t dst;
+                if (p.r <= 1) {
+                    dst = pix * p.out_cs + p.out_coff + c0;
+                } else {   // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c, Cd % 4 == 0 here
+                    const int sub = c0 / p.Cd, c = c0 - sub * p.Cd;
+                    const int i = sub / p.r, j = sub - i * p.r;
+                    dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs + p.out_coff + c;
+                }
+                store4<bf16_t>(p.out, dst, true, 4, v, p.out_f32 != 0);
+            }
+        }
+    }
+}
+
+constexpr int ROWS_R = 6;   // 24 x 16 output tile per workgroup: 48/96/192-pixel patches tile exactly
+
+template <int NB16>
+int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
+    constexpr int R = ROWS_R;
+    constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024;
+    ConvParams p = p0;
+    p.tilesX = (p.W + 15) / 16;
+    p.tilesY = (p.H + 4 * R - 1) / (4 * R);
+    auto kern = conv3_rows_kernel<NB16, R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+}  // namespace
+
+int conv_rows_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams& p, hipStream_t st) {
+    const int nct = w.CoutP / 16 / w.NT;   // NT holds NB16 for this variant
+    switch (w.NT) {
+        case 1: return launch_rows<1>(ctx, p, nct, st);
+        case 2: return launch_rows<2>(ctx, p, nct, st);
+        case 4: return launch_rows<4>(ctx, p, nct, st);
+    }
+    return ctx->fail(SR_ERR_INVALID, "conv_rows: unsupported cout block count");
+}

@@ -1,0 +1,71 @@
+"""Patch-wise inference plumbing shared by the three SR wrappers and the classifier.
+
+Device restatement of the helper trio every reference `super_resolve_image` defines locally
+(add_padding / extract_patches / reconstruct_from_patches: SRCNN_model.py:127-188,
+EDSR_model.py:201-256, ESRGAN_model.py:883-921).  Patches are cut, pushed through the model and
+overlap-averaged without leaving the GPU; only the reference's NumPy-in / NumPy-out contract at
+the very edge copies over PCIe.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .runtime import Context
+
+
+def pad_amount(n, patch, stride):
+    """loading_methods.py:12-17."""
+    pad = (patch - (n % stride)) % stride if n % stride != 0 else 0
+    return max(pad, patch - stride)
+
+
+def patch_grid(h, w, patch, stride):
+    """number of window positions (rows, cols) over the reflect-padded image."""
+    hp, wp = h + pad_amount(h, patch, stride), w + pad_amount(w, patch, stride)
+    return len(range(0, hp - patch + 1, stride)), len(range(0, wp - patch + 1, stride))
+
+
+def as_device_image(ctx, img):
+    """Reference inputs: np.ndarray RGB, uint8 [0,255] or float; tensors pass through."""
+    if isinstance(img, torch.Tensor):
+        return img.to(ctx.torch_device, torch.float32).contiguous(), False
+    a = np.asarray(img)
+    return ctx.to_device(a.astype(np.float32, copy=False)), True
+
+
+def inference_metrics(ctx, elapsed, mem_begin, mem_end):
+    """Same keys and arithmetic as the reference's metrics dict (SRCNN_model.py:215-242); memory is
+    what libsr355 holds on the device (weights + workspaces)."""
+    mb = lambda x: float(x) / (1024.0 * 1024.0)
+    return {
+        "time_sec": float(elapsed),
+        "gpu_mean_current_mb": mb((mem_begin["current"] + mem_end["current"]) / 2.0),
+        "gpu_peak_mb": mb(max(mem_begin["peak"], mem_end["peak"])),
+    }
+
+
+def patchwise_sr(model, lr, patch, stride, scale, chunk, in_mul=1.0, in_add=0.0, out_mul=1.0, out_add=0.0):
+    """lr [H,W,3] fp32 device tensor in [0,1] -> (sr [H*scale,W*scale,3] fp32 device tensor, metrics)."""
+    ctx = model.ctx
+    H, W, _ = lr.shape
+    patches = ctx.extract_patches(lr, patch, stride, mul=in_mul, add=in_add)
+    mem0 = ctx.mem_info()
+    torch.cuda.synchronize(ctx.torch_device)
+    t0 = time.perf_counter()
+    hr = model.predict(patches, batch_size=chunk)
+    torch.cuda.synchronize(ctx.torch_device)
+    elapsed = time.perf_counter() - t0
+    sr = ctx.overlap_add(hr, H, W, patch, stride, scale, mul=out_mul, add=out_add)
+    return sr, inference_metrics(ctx, elapsed, mem0, ctx.mem_info())
+
+
+def majority_vote(probs):
+    """VGG16_model.py:252-268 on host (a handful of scalars)."""
+    probs = np.asarray(probs)
+    if probs.ndim != 2:
+        probs = probs.reshape((probs.shape[0], -1))
+    votes = np.bincount(np.argmax(probs, axis=1), minlength=int(probs.shape[1]))
+    tied = np.where(votes == votes.max())[0]
+    win = int(tied[0]) if len(tied) == 1 else int(tied[np.argmax(probs.mean(axis=0)[tied])])
+    return win, float(probs[:, win].mean())

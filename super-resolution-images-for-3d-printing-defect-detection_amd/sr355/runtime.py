@@ -93,6 +93,16 @@ class Context:
         self.check(self.lib.sr_last_forward_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def profile_begin(self):
+        self.check(self.lib.sr_profile_begin(self.h))
+
+    def profile_end(self):
+        """-> [{'kernel','launches','total_ms','flops','bytes'}] per kernel template instance (HIP-event timed)."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self.lib.sr_profile_end(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     # ------------------------------------------------------------------ single ops
     def conv2d(self, x, w, b=None, act="linear", alpha=1.0, skip1=None, beta1=0.0, skip2=None, beta2=0.0,
                clip01=False, d2s=1):
