@@ -131,11 +131,11 @@ def self_attention(x, wf, bf, wg, bg, wh, bh, wv, bv, dtype=np.float32, return_p
     f = conv2d(x, wf, bf, dtype=dtype).reshape(B, H * W, -1)
     g = conv2d(x, wg, bg, dtype=dtype).reshape(B, H * W, -1)
     h = conv2d(x, wh, bh, dtype=dtype).reshape(B, H * W, -1)
-    s = np.einsum("bnd,bmd->bnm", g, f)                      # g rows (queries), f cols (keys)
-    s = s - s.max(axis=-1, keepdims=True)
-    e = np.exp(s)
-    beta = e / e.sum(axis=-1, keepdims=True)
-    o = np.einsum("bnm,bmd->bnd", beta, h).reshape(B, H, W, -1).astype(dtype)
+    s = np.matmul(g, f.transpose(0, 2, 1))                   # [B,N,N]: g rows (queries), f cols (keys)
+    s -= s.max(axis=-1, keepdims=True)
+    np.exp(s, out=s)
+    s /= s.sum(axis=-1, keepdims=True)                       # beta
+    o = np.matmul(s, h).reshape(B, H, W, -1).astype(dtype)
     ov = conv2d(o, wv, bv, dtype=dtype)
     y = x + ov
     if return_parts:

@@ -1,0 +1,51 @@
+"""The C-ABI shared library: loads on a CPU-only box and exports every symbol include/sr355.h declares
+(no compute calls here: there is no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sr355.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    from sr355 import _lib
+    assert header_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_loads_and_exports_everything():
+    from sr355 import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.load()
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_init_without_gpu_fails_cleanly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sr355 import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.sr_init(0, ctypes.byref(h)) != 0 and not h.value
+    from sr355 import Context
+    with pytest.raises(RuntimeError):
+        Context.get()
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from sr355 import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libsr355.so"))
+    with pytest.raises(ImportError):
+        _lib.load()

@@ -1,0 +1,119 @@
+"""The reference-shaped classes (SRModels/*) end to end on the GPU: super_resolve_image / evaluate / classify /
+metrics against the oracle pipelines, plus the reference's guard exceptions."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as M
+from oracle import ops as O
+from sr355.synth import make_pairs
+from sr355.weights import bf16_rounded
+
+pytestmark = pytest.mark.gpu
+
+
+def test_metrics_module(ctx):
+    from SRModels.metrics import psnr, ssim
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 1, (2, 24, 24, 3)).astype(np.float32)
+    b = np.clip(a + 0.05 * rng.standard_normal(a.shape), 0, 1).astype(np.float32)
+    assert np.allclose(psnr(a, b), O.psnr(a, b, dtype=np.float64), atol=2e-4)
+    assert np.allclose(ssim(a, b), O.ssim(a, b, dtype=np.float64), atol=5e-5)
+    assert psnr(a[0], b[0]).shape == ()
+
+
+def test_bicubic_cfg0_plumbing(ctx):
+    """BASELINE configs[0]: bicubic 64x64 -> 256x256 + PSNR/SSIM against the HR tile."""
+    from SRModels.classic_super_resolution_algorithms.classic_algorithms import interpolate_bicubic
+    from SRModels.metrics import psnr, ssim
+    lr, hr = make_pairs(1, 64, 64, 4, seed=42)
+    up = interpolate_bicubic(lr[0], (256, 256))
+    ref = O.bicubic_resize(lr[0], 256, 256)
+    assert np.max(np.abs(up - ref)) <= 2e-6
+    assert abs(float(psnr(hr[0], up)) - float(O.psnr(hr[0], ref, dtype=np.float64))) <= 1e-3
+    assert abs(float(ssim(hr[0], up)) - float(O.ssim(hr[0], ref, dtype=np.float64))) <= 1e-4
+    u8 = (lr[0] * 255).astype(np.uint8)
+    assert np.array_equal(interpolate_bicubic(u8, (256, 256)), O.bicubic_resize_u8(u8, 256, 256))
+
+
+def test_srcnn_wrapper(ctx, tmp_path):
+    from SRModels.deep_learning_models.SRCNN_model import SRCNNModel
+    m = SRCNNModel()
+    with pytest.raises(ValueError):
+        m.setup_model()
+    with pytest.raises(FileNotFoundError):
+        m.setup_model(from_pretrained=True, pretrained_path=str(tmp_path / "none.npz"))
+    m.setup_model(input_shape=(24, 24, 3))
+    lr, hr = make_pairs(1, 30, 26, 2, seed=3)
+    with pytest.raises(RuntimeError):
+        m.super_resolve_image(lr[0], 60, 52)
+    m.set_weights(m.weights)
+    with pytest.raises(ValueError):
+        m.super_resolve_image([[1, 2]], 60, 52)
+    sr, met = m.super_resolve_image(lr[0], 60, 52)
+    ref = M.srcnn_super_resolve(lr[0], m.weights, 60, 52, dtype=np.float64)
+    assert sr.shape == (60, 52, 3) and np.max(np.abs(sr - ref)) <= 1e-5
+    assert set(met) == {"time_sec", "gpu_mean_current_mb", "gpu_peak_mb"} and met["gpu_peak_mb"] > 0
+    # evaluate == keras [mse, psnr, ssim] sample-weighted means
+    X = np.random.default_rng(1).uniform(0, 1, (5, 24, 24, 3)).astype(np.float32)
+    Y = np.clip(X + 0.02, 0, 1)
+    res = m.evaluate(X, Y)
+    P_ = M.srcnn_forward(X, m.weights, dtype=np.float64)
+    assert np.isclose(res[0], np.mean((P_ - Y) ** 2), rtol=1e-4)
+    assert np.isclose(res[1], O.psnr(Y, P_, dtype=np.float64).mean(), atol=1e-3)
+    assert np.isclose(res[2], O.ssim(Y, P_, dtype=np.float64).mean(), atol=1e-4)
+    path = m.save(str(tmp_path), "t0")
+    m2 = SRCNNModel()
+    m2.setup_model(from_pretrained=True, pretrained_path=path)
+    sr2, _ = m2.super_resolve_image(lr[0], 60, 52)
+    assert np.array_equal(sr, sr2)
+
+
+def test_edsr_wrapper(ctx):
+    from SRModels.deep_learning_models.EDSR_model import EDSR
+    m = EDSR()
+    with pytest.raises(ValueError):
+        m.setup_model(scale_factor=5)
+    m.setup_model(scale_factor=4, num_res_blocks=2)
+    m.set_weights(m.weights)
+    lr, _ = make_pairs(1, 50, 37, 4, seed=4)
+    sr, _ = m.super_resolve_image(lr[0], patch_size_lr=24, stride=12)
+    ref = M.edsr_super_resolve(lr[0], m.weights, 4, 24, 12, num_res_blocks=2, dtype=np.float64)
+    assert sr.shape == (200, 148, 3) and np.max(np.abs(sr - ref)) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("bf16", 2e-2)])
+def test_esrgan_wrapper(ctx, dtype, tol):
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    m = ESRGAN(compute_dtype=dtype)
+    m.setup_model(scale_factor=2, growth_channels=8, num_rrdb_blocks=4)      # the notebook's configuration
+    lr, hr = make_pairs(1, 40, 52, 2, seed=5)
+    with pytest.raises(RuntimeError):
+        m.super_resolve_image(lr[0])
+    w = bf16_rounded(m.weights) if dtype == "bf16" else m.weights
+    m.set_weights(w)
+    sr, met = m.super_resolve_image(lr[0], patch_size_lr=24, stride=12, batch_size=16)
+    ref = M.esrgan_super_resolve(lr[0], w, 2, 24, 12, num_rrdb=4, dtype=np.float64)
+    assert sr.shape == (80, 104, 3) and sr.min() >= 0 and sr.max() <= 1
+    assert np.max(np.abs(sr - ref)) <= tol
+    # north-star parity metric: |PSNR(gpu,HR) - PSNR(oracle,HR)| <= 0.01 dB
+    d = abs(float(O.psnr(hr[0], sr, dtype=np.float64)) - float(O.psnr(hr[0], ref, dtype=np.float64)))
+    assert d <= 0.01, d
+    # device-tensor in -> device-tensor out, same numbers
+    sr_t, _ = m.super_resolve_image(ctx.to_device(lr[0]), patch_size_lr=24, stride=12)
+    assert isinstance(sr_t, torch.Tensor) and np.array_equal(sr_t.cpu().numpy(), sr)
+    ev = m.evaluate([(lr[:1, :24, :24] * 2 - 1, hr[:1, :48, :48] * 2 - 1)])
+    assert set(ev) == {"avg_psnr", "avg_ssim", "avg_g_loss"}
+
+
+def test_vgg16_wrapper(ctx):
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN  # noqa: F401  (import check of the sibling module)
+    from SRModels.defect_detection_models.VGG16_model import FineTunedVGG16
+    m = FineTunedVGG16()
+    m.setup_model(input_shape=(96, 96, 3), num_classes=2)
+    img = make_pairs(1, 60, 50, 4, seed=6)[1][0]           # 240 x 200 "SR output"
+    with pytest.raises(ValueError):
+        m.classify_defects_method(img[:, :, 0])
+    cls, conf = m.classify_defects_method(img, patch_size=96, stride=48)
+    rcls, rconf = M.classify_defects(img, m.weights, 96, 48, dtype=np.float64)
+    assert cls == rcls and abs(conf - rconf) <= 1e-4
