@@ -41,7 +41,14 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     char* lw = smem + LIN_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, px = lane & 15, q = lane >> 4;
-    int t = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run
+    // of the tile list -- the tiles of one image then share an L2 and their halo re-reads stay on chip.
+    int t;
+    {
+        const int total = gridDim.x, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int qn = total >> 3, rn = total & 7;
+        t = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + k;
+    }
     const int tx = t % p.tilesX; t /= p.tilesX;
     const int ty = t % p.tilesY;
     const int b = t / p.tilesY;
@@ -168,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
         return;
     }
     // fast path: 4-channel vectors everywhere; skips are loaded for a group of rows before any of them is used
-    constexpr int RG = NB16 == 4 ? 3 : R;
+    constexpr int RG = NB16 == 4 ? 2 : R;
     const bool has1 = p.s1 != nullptr, has2 = p.s2 != nullptr;
     const bf16_t* s1p = reinterpret_cast<const bf16_t*>(p.s1);
     const bf16_t* s2p = reinterpret_cast<const bf16_t*>(p.s2);
@@ -227,11 +234,11 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     }
 }
 
-constexpr int ROWS_R = 6;   // 24 x 16 output tile per workgroup: 48/96/192-pixel patches tile exactly
-
+// rows per wave: 24 x 16 output tiles (16 x 16 for 64 couts per workgroup, to stay inside 256 VGPRs without spills);
+// 48/96/192-pixel patches tile exactly either way
 template <int NB16>
 int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
-    constexpr int R = ROWS_R;
+    constexpr int R = NB16 == 4 ? 4 : 6;
     constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024;
     ConvParams p = p0;
     p.tilesX = (p.W + 15) / 16;
