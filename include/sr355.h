@@ -73,6 +73,9 @@ int  sr_last_forward_ms(sr_ctx* ctx, float* ms);
  * begin: start collecting; end: synchronise the device and write a JSON array
  * [{"kernel","launches","total_ms","flops","bytes"}...] (algorithmic FLOP / HBM bytes per kernel
  * template instance) into `json` (capacity `cap` bytes). */
+/* Diagnostic only (never set in production): a device buffer of 16 uint64 per workgroup of the next 3x3 bf16 conv
+ * launches; a separately compiled stamped variant of the kernel writes s_memtime stamps there (NULL switches back). */
+int  sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer);
 int  sr_profile_begin(sr_ctx* ctx);
 int  sr_profile_end(sr_ctx* ctx, char* json, int64_t cap);
 

@@ -360,6 +360,12 @@ int sr_last_forward_ms(sr_ctx* ctx, float* ms) {
     return SR_OK;
 }
 
+int sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer) {
+    if (!ctx) return SR_ERR_INVALID;
+    ctx->stamp_buf = static_cast<unsigned long long*>(device_u64_buffer);
+    return SR_OK;
+}
+
 int sr_profile_begin(sr_ctx* ctx) {
     if (!ctx) return SR_ERR_INVALID;
     for (auto& r : ctx->prof_recs) { ctx->ev_pool.push_back(r.e0); ctx->ev_pool.push_back(r.e1); }

@@ -27,6 +27,7 @@ struct sr_ctx {
 
     void* scratch_buf = nullptr;
     size_t scratch_cap = 0;
+    unsigned long long* stamp_buf = nullptr;   // diagnostic: when set, conv3_rows runs its stamped variant
 
     // per-launch HIP-event timing of the hot kernels (sr_profile_begin/_end)
     struct ProfRec { int name; hipEvent_t e0, e1; double flops, bytes; };

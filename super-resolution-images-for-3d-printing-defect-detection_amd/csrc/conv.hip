@@ -443,6 +443,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.s2 = static_cast<const char*>(ep.skip2.p); p.s2_cs = ep.skip2.cs; p.s2_coff = ep.skip2.coff; p.beta2 = ep.beta2;
     p.alpha = ep.alpha; p.act = ep.act; p.clip = ep.clip01; p.r = r; p.Cd = w.Cout / (r * r);
     p.B = B; p.H = H; p.W = W; p.Cout = w.Cout; p.nchunks = w.nchunks; p.tilesX = p.tilesY = 0;
+    p.dbg = ctx->stamp_buf;
     const int osz = p.out_f32 ? 4 : esz;
     bool vec = (y_cs % 4 == 0) && (y_coff % 4 == 0) && ((uintptr_t)y % (4 * osz) == 0) && (p.Cd % 4 == 0);
     if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);

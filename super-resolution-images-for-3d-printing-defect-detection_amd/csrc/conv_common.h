@@ -15,6 +15,7 @@ struct ConvParams {
     int nchunks;        // wide: Cin chunks; thin: number of k-groups (taps pairs)
     int tilesX, tilesY;
     int vec;            // epilogue may use 4-element vector loads/stores
+    unsigned long long* dbg;   // diagnostic builds only: 16 s_memtime stamps per workgroup (sr_debug_set_stamp_buffer)
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {

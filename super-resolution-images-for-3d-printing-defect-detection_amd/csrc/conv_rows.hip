@@ -16,8 +16,13 @@
 // LDS image of the input halo tile: pixel-major, 64 B per pixel per chunk, no padding; 16-byte slice q
 // of pixel index t (t = row*18 + col) sits at t*64 + ((q*16) ^ ((t & 4) << 3)).  With that XOR the 16
 // lanes a ds_read_b128 services together hit 16 distinct 16-byte bank slots for every tap offset
-// (checked exhaustively over all shifts), and a staging wave still writes 1 KiB contiguously.
-// Weights are host-packed lane-linear per (chunk, tap, cout-block-of-16): a straight copy, conflict free.
+// (checked exhaustively over all shifts; SQ_LDS_BANK_CONFLICT = 0 measured), and a staging wave still
+// writes 1 KiB contiguously.  Weights are host-packed lane-linear per (chunk, tap, cout-block-of-16): a
+// straight copy, conflict free.
+//
+// Prologue and epilogue are kept to a few hundred issue slots per wave (32-bit offsets from wave-uniform
+// 64-bit bases, branch-free activation, biases prefetched, skips loaded in bulk): in-kernel stamps showed
+// they, not the MFMAs, held the SIMDs in the first version.
 #include "conv_common.h"
 
 namespace {
@@ -28,7 +33,9 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NB16, int R>
+#define STAMP_AT(i) do { if (STAMP && tid == 0) p.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <int NB16, int R, bool STAMP>
 __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     constexpr int TH = 4 * R, TW = 16, PH = TH + 2, PW = TW + 2;
     constexpr int NPIX = PH * PW;
@@ -36,11 +43,14 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     constexpr int NINT = (NIN + 255) / 256;
     constexpr int LIN_BYTES = NPIX * 64;
     constexpr int WUNITS = 9 * NB16 * 64;         // 16-byte units of weights per chunk
+    constexpr int NWT = (WUNITS + 255) / 256;     // weight units per thread
+    constexpr bool WPRE = NB16 <= 2;              // prefetch next chunk's weights into registers when they fit
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lin = smem;
     char* lw = smem + LIN_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, px = lane & 15, q = lane >> 4;
+    STAMP_AT(0);
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run
     // of the tile list -- the tiles of one image then share an L2 and their halo re-reads stay on chip.
     int t;
@@ -54,9 +64,10 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     const int b = t / p.tilesY;
     const int ct = blockIdx.y;
     const int y0 = ty * TH, x0 = tx * TW;
-    const bf16_t* inb = reinterpret_cast<const bf16_t*>(p.in) + (int64_t)b * p.H * p.W * p.in_cs + p.in_coff;
+    const int H = p.H, W = p.W, in_cs = (int)p.in_cs;
+    const bf16_t* inb = reinterpret_cast<const bf16_t*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;   // wave-uniform
 
-    int soff[NINT], doff[NINT];
+    int soff[NINT], doff[NINT];   // 32-bit element offset inside the image (-1: zero fill) / LDS byte offset (-1: none)
 #pragma unroll
     for (int i = 0; i < NINT; ++i) {
         const int u = tid + 256 * i;
@@ -64,12 +75,10 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
         const int py = pix / PW, pxx = pix - py * PW;
         const int gy = y0 + py - 1, gx = x0 + pxx - 1;
         const bool live = u < NIN;
-        const bool inside = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool inside = live && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         doff[i] = live ? pix * 64 + ((sl * 16) ^ ((pix & 4) << 3)) : -1;
-        soff[i] = inside ? (int)(((int64_t)gy * p.W + gx) * p.in_cs) + sl * 8 : -1;
+        soff[i] = inside ? (gy * W + gx) * in_cs + sl * 8 : -1;
     }
-    constexpr int NWT = (WUNITS + 255) / 256;     // weight units per thread
-    constexpr bool WPRE = NB16 <= 2;              // prefetch next chunk's weights into registers when they fit
     bf16x8 pre[NINT];
     f32x4 wpre[NWT];
     const char* wbase = p.w + (int64_t)ct * p.nchunks * (int64_t)(WUNITS * 16);
@@ -77,7 +86,7 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < NINT; ++i) {
             const int so = soff[i];
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (so >= 0 ? so + chunk * 32 : 0));
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (so >= 0 ? so + chunk * 32 : 0));   // always a valid address
             bf16x8 z = {};
             pre[i] = so >= 0 ? v : z;
         }
@@ -98,6 +107,13 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
         }
     };
 
+    issue(0);
+    if (WPRE) issue_w(0);
+    // this lane's 4 biases per cout block, fetched now so the epilogue never waits on them
+    f32x4 biasv[NB16];
+#pragma unroll
+    for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(p.bias + (ct * NB16 + n) * 16 + 4 * q);
+
     f32x4 acc[R][NB16];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -110,22 +126,18 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
         const int tt = tbase + yi * PW + kx;
         return tt * 64 + ((q * 16) ^ ((tt & 4) << 3));
     };
+    STAMP_AT(1);
 
-    // this lane's 4 biases per cout block, fetched before the main loop so the epilogue never waits on them
-    f32x4 biasv[NB16];
-#pragma unroll
-    for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(p.bias + (ct * NB16 + n) * 16 + 4 * q);
-
-    issue(0);
-    if (WPRE) issue_w(0);
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         __syncthreads();
+        if (chunk < 6) STAMP_AT(2 + 2 * chunk);
 #pragma unroll
         for (int i = 0; i < NINT; ++i)
             if (doff[i] >= 0) *reinterpret_cast<bf16x8*>(lin + doff[i]) = pre[i];
         if (!WPRE) issue_w(chunk);     // all loads in flight together, one exposed latency per chunk
         write_w();
         __syncthreads();
+        if (chunk < 6) STAMP_AT(3 + 2 * chunk);
         if (chunk + 1 < p.nchunks) {
             issue(chunk + 1);
             if (WPRE) issue_w(chunk + 1);
@@ -156,15 +168,19 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
             }
         }
     }
+    STAMP_AT(14);
+
     // ---- epilogue.  lane (px, q): pixel column px, couts 4q..4q+3 of each 16-block.
     const int ox = x0 + px;
-    const bool fast = p.vec != 0 && (p.Cout & 3) == 0;
-    if (!fast) {   // odd channel counts / unaligned views: generic per-element path (final RGB conv)
-        if (ox < p.W) {
+    const int oyw = y0 + wave * R;                         // first output row of this wave (wave-uniform)
+    const int Cd = p.Cd, rr_ = p.r;
+    const bool fast = p.vec != 0 && (p.Cout & 3) == 0 && p.act != SR_ACT_TANH && (rr_ <= 1 || (Cd & 15) == 0);
+    if (!fast) {   // odd channel counts / unaligned views / tanh: generic per-element path (final RGB conv)
+        if (ox < W) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int oy = y0 + wave * R + r;
-                if (oy >= p.H) continue;
+                const int oy = oyw + r;
+                if (oy >= H) continue;
 #pragma unroll
                 for (int n = 0; n < NB16; ++n) {
                     const float a[4] = {acc[r][n][0], acc[r][n][1], acc[r][n][2], acc[r][n][3]};
@@ -172,66 +188,86 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
                 }
             }
         }
+        STAMP_AT(15);
         return;
     }
-    // fast path: 4-channel vectors everywhere; skips are loaded for a group of rows before any of them is used
+    // fast path.  Activation is branch-free: max(v, slope*v) with slope 1 (linear), 0 (relu), 0.2 (leaky relu).
+    const float slope = p.act == SR_ACT_RELU ? 0.f : (p.act == SR_ACT_LRELU ? 0.2f : 1.f);
+    const float alpha = p.alpha, beta1 = p.beta1, beta2 = p.beta2;
+    const bool has1 = p.s1 != nullptr, has2 = p.s2 != nullptr, clip = p.clip != 0, of32 = p.out_f32 != 0;
+    const int rows = min(R, H - oyw);                     // wave-uniform count of live rows (<= 0: nothing to do)
+    const bool col_ok = ox < W;
+    const int64_t img_pix = (int64_t)b * H * W;           // wave-uniform
+    int c0[NB16];                                         // first cout of this lane in each block
+#pragma unroll
+    for (int n = 0; n < NB16; ++n) c0[n] = (ct * NB16 + n) * 16 + 4 * q;
     constexpr int RG = NB16 == 4 ? 2 : R;
-    const bool has1 = p.s1 != nullptr, has2 = p.s2 != nullptr;
-    const bf16_t* s1p = reinterpret_cast<const bf16_t*>(p.s1);
-    const bf16_t* s2p = reinterpret_cast<const bf16_t*>(p.s2);
 #pragma unroll
     for (int r0 = 0; r0 < R; r0 += RG) {
         bf16x4 k1[RG][NB16], k2[RG][NB16];
         if (has1 || has2) {
 #pragma unroll
             for (int rr = 0; rr < RG; ++rr) {
-                const int oy = y0 + wave * R + r0 + rr;
-                const bool ok = oy < p.H && ox < p.W;
-                const int64_t pix = ok ? ((int64_t)b * p.H + oy) * p.W + ox : (int64_t)b * p.H * p.W;
+                const int r = r0 + rr;
+                const bool ok = r < rows && col_ok;
+                const int64_t rowpix = img_pix + (int64_t)(r < rows ? oyw + r : 0) * W;   // dead rows read row 0: valid memory
+                const int oxc = ok ? ox : 0;
 #pragma unroll
                 for (int n = 0; n < NB16; ++n) {
-                    const int c0 = min((ct * NB16 + n) * 16 + 4 * q, p.Cout - 4);
-                    if (has1) k1[rr][n] = *reinterpret_cast<const bf16x4*>(s1p + pix * p.s1_cs + p.s1_coff + c0);
-                    if (has2) k2[rr][n] = *reinterpret_cast<const bf16x4*>(s2p + pix * p.s2_cs + p.s2_coff + c0);
+                    const int cc = min(c0[n], p.Cout - 4);
+                    if (has1) k1[rr][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s1) + rowpix * p.s1_cs +
+                                                                          (oxc * (int)p.s1_cs + p.s1_coff + cc));
+                    if (has2) k2[rr][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s2) + rowpix * p.s2_cs +
+                                                                          (oxc * (int)p.s2_cs + p.s2_coff + cc));
                 }
             }
         }
 #pragma unroll
         for (int rr = 0; rr < RG; ++rr) {
-            const int oy = y0 + wave * R + r0 + rr;
-            if (oy >= p.H || ox >= p.W) continue;
-            const int64_t pix = ((int64_t)b * p.H + oy) * p.W + ox;
+            const int r = r0 + rr;
+            if (r < rows) {                                  // wave-uniform
+                const int oy = oyw + r;
 #pragma unroll
-            for (int n = 0; n < NB16; ++n) {
-                const int c0 = (ct * NB16 + n) * 16 + 4 * q;
-                if (c0 >= p.Cout) continue;
-                float v[4];
+                for (int n = 0; n < NB16; ++n) {
+                    f32x4 v = acc[r][n] + biasv[n];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[r0 + rr][n][e] + biasv[n][e], p.act) * p.alpha;
-                if (has1) {
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope) * alpha;
+                    if (has1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.beta1 * (float)k1[rr][n][e];
+                        for (int e = 0; e < 4; ++e) v[e] += beta1 * (float)k1[rr][n][e];
+                    }
+                    if (has2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += beta2 * (float)k2[rr][n][e];
+                    }
+                    if (clip) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+                    }
+                    int64_t rowbase;    // wave-uniform element index of the output row start
+                    int loff;           // per-lane offset inside the row
+                    if (rr_ <= 1) {
+                        rowbase = (img_pix + (int64_t)oy * W) * p.out_cs;
+                        loff = ox * (int)p.out_cs + p.out_coff + c0[n];
+                    } else {            // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c; Cd % 16 == 0 -> (i,j) uniform per block
+                        const int blk = (ct * NB16 + n) * 16, sub = blk / Cd, cb = blk - sub * Cd;
+                        const int i = sub / rr_, j = sub - i * rr_;
+                        rowbase = (img_pix * rr_ * rr_ + ((int64_t)oy * rr_ + i) * ((int64_t)W * rr_)) * p.out_cs;
+                        loff = (ox * rr_ + j) * (int)p.out_cs + p.out_coff + cb + 4 * q;
+                    }
+                    if (col_ok && c0[n] < p.Cout) {
+                        if (of32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + rowbase + loff) = v;
+                        } else {
+                            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + rowbase + loff) = o;
+                        }
+                    }
                 }
-                if (has2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.beta2 * (float)k2[rr][n][e];
-                }
-                if (p.clip) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
-                }
-                int64_t dst;
-                if (p.r <= 1) {
-                    dst = pix * p.out_cs + p.out_coff + c0;
-                } else {   // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c, Cd % 4 == 0 here
-                    const int sub = c0 / p.Cd, c = c0 - sub * p.Cd;
-                    const int i = sub / p.r, j = sub - i * p.r;
-                    dst = (((int64_t)b * p.H * p.r + (int64_t)oy * p.r + i) * ((int64_t)p.W * p.r) + (int64_t)ox * p.r + j) * p.out_cs + p.out_coff + c;
-                }
-                store4<bf16_t>(p.out, dst, true, 4, v, p.out_f32 != 0);
             }
         }
     }
+    STAMP_AT(15);
 }
 
 // rows per wave: 24 x 16 output tiles (16 x 16 for 64 couts per workgroup, to stay inside 256 VGPRs without spills);
@@ -243,13 +279,20 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     ConvParams p = p0;
     p.tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 4 * R - 1) / (4 * R);
-    auto kern = conv3_rows_kernel<NB16, R>;
+    dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
+    if (p.dbg) {   // diagnostic stamped variant
+        auto kd = conv3_rows_kernel<NB16, R, true>;
+        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kd, grid, dim3(256), lds, st, p);
+        SR_HIP(ctx, hipGetLastError());
+        return SR_OK;
+    }
+    auto kern = conv3_rows_kernel<NB16, R, false>;
     static bool attr_set = false;
     if (!attr_set) {
         SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;

@@ -34,6 +34,7 @@ SIGNATURES = {
     "sr_last_error": (C.c_char_p, [_vp]),
     "sr_mem_info": (_i, [_vp, _i64p, _i64p]),
     "sr_last_forward_ms": (_i, [_vp, _fp]),
+    "sr_debug_set_stamp_buffer": (_i, [_vp, _vp]),
     "sr_profile_begin": (_i, [_vp]),
     "sr_profile_end": (_i, [_vp, C.c_char_p, _i64]),
     "sr_model_create": (_i, [_vp, _i, C.POINTER(ModelCfg), C.POINTER(_vp)]),
