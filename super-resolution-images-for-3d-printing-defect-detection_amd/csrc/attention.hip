@@ -16,6 +16,8 @@
 // exp count B*N^2 (the binding resource: d_qk/d_v are tiny).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int KV_TILE = 64;
@@ -166,6 +168,160 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 production kernel.  Same formulation; tuned for the binding resource (VALU / v_exp_f32 issue):
+//   * a wave owns TWO 32-query blocks (64 queries): every key fragment load, V^T fragment read and
+//     barrier is shared by both; workgroup = 256 queries, key tile = 128 keys per barrier;
+//   * softmax in the exp2 domain: p = exp2(s*log2e - m'), one fma + one v_exp_f32 per score;
+//   * the O/l rescale runs only when some lane's running max actually grew (wave-uniform vote), which
+//     after the first few key tiles is rare; the result is bit-identical to rescaling every tile
+//     because exp2(0) = 1 exactly;
+//   * key masking (-inf) only on the ragged last tile; key fragments are fetched one tile ahead;
+//   * V is transposed into LDS two keys per dword (8 ds_write_b32 per thread per 128 keys).
+// ------------------------------------------------------------------------------------------------
+constexpr int KT2 = 128;                       // keys per barrier
+constexpr int PITCH2 = KT2 * 2 + 8;            // bytes per V^T row: 66 dwords -> conflict-free ds_read_b64
+
+__global__ void __launch_bounds__(256) attn_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char vt[32 * PITCH2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int N = p.N;
+    const int nqt = (N + 255) / 256;
+    const int b = blockIdx.x / nqt, qt = blockIdx.x - b * nqt;
+    const bf16_t* base = reinterpret_cast<const bf16_t*>(p.qkv) + (int64_t)b * N * p.cs;
+    const int cs = (int)p.cs;
+    const float LOG2E = 1.4426950408889634f;
+
+    int qi[2];
+    bf16x8 qb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        qi[j] = qt * 256 + wave * 64 + j * 32 + r;
+        const int qc = qi[j] < N ? qi[j] : N - 1;
+        bf16x8 z = {};
+        qb[j] = z;
+        if (h == 0) qb[j] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qc * cs + p.qoff);
+    }
+    f32x16 oacc[2];
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
+
+    const int kp = tid >> 2, oct = tid & 3;    // V staging: key pair, 8-channel octet
+    auto load_k = [&](int kb) {
+        bf16x8 kf = {};
+        const int key = kb + r;
+        if (h == 0) kf = *reinterpret_cast<const bf16x8*>(base + (int64_t)(key < N ? key : N - 1) * cs + p.koff);
+        return kf;
+    };
+    bf16x8 knext = load_k(0);
+    f32x16 zero16;                                     // loop-invariant C operand of the score MFMA (never written)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+    struct { } false_c; struct { int x; } true_c{0};
+    // max over the two lane halves without the LDS crossbar: v_permlane32_swap is a plain VALU op
+    auto hmax = [](float v) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    };
+    auto tile = [&](const bf16x8 kf, const int sub, const int kb, auto ragged_tag) {
+        constexpr bool RAGGED = sizeof(ragged_tag) > 1;
+        // phase A (both query blocks, no control flow in between): scores and their column maxima
+        f32x16 s[2];
+        float mx[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb[j], zero16, 0, 0, 0);
+            if constexpr (RAGGED) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (kb + (i & 3) + 8 * (i >> 2) + 4 * h >= N) s[j][i] = -INFINITY;
+            }
+            float m = fmaxf(fmaxf(s[j][0], s[j][1]), s[j][2]);
+#pragma unroll
+            for (int i = 3; i + 1 < 16; i += 2) m = fmaxf(fmaxf(m, s[j][i]), s[j][i + 1]);
+            m = fmaxf(m, s[j][15]);
+            mx[j] = hmax(m) * LOG2E;
+        }
+        // phase B: one wave-uniform vote for both blocks; rescale only when a running max grew
+        if (__any(mx[0] > m_run[0] || mx[1] > m_run[1])) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float m_new = fmaxf(m_run[j], mx[j]);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);   // exp2(-inf) = 0 first; exp2(0) = 1 exactly
+                l_run[j] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[j][e] *= alpha;
+                m_run[j] = m_new;
+            }
+        }
+        // phase C (both blocks interleavable): probabilities, row sums, O^T += V^T . P^T
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float nm = -m_run[j];
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[j][i] = __builtin_amdgcn_exp2f(fmaf(s[j][i], LOG2E, nm)); psum += s[j][i]; }
+            l_run[j] += psum;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char* vrow = vt + r * PITCH2 + (sub * 32 + 16 * ks + 4 * h) * 2;
+            const bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow);
+            const bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + 16);
+            const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[j][8 * ks + e];
+                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[j], 0, 0, 0);
+            }
+        }
+    };
+
+    for (int k0 = 0; k0 < N; k0 += KT2) {
+        __syncthreads();
+        {
+            const int ka = k0 + 2 * kp, kbb = ka + 1;
+            const bf16x8 va = *reinterpret_cast<const bf16x8*>(base + (int64_t)(ka < N ? ka : N - 1) * cs + p.voff + oct * 8);
+            const bf16x8 vb = *reinterpret_cast<const bf16x8*>(base + (int64_t)(kbb < N ? kbb : N - 1) * cs + p.voff + oct * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 pr = {va[e], vb[e]};
+                *reinterpret_cast<bf16x2*>(vt + (oct * 8 + e) * PITCH2 + kp * 4) = pr;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < KT2 / 32; ++sub) {
+            const int kb = k0 + sub * 32;
+            if (kb >= N) break;
+            const bf16x8 kf = knext;
+            knext = load_k(kb + 32);                       // next tile's keys fly under this tile's softmax
+            if (kb + 32 <= N) tile(kf, sub, kb, false_c);  // full tile: no masking code at all
+            else tile(kf, sub, kb, true_c);                // ragged last tile: keys >= N get -inf
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float inv = 1.f / (l_run[j] + xhalf(l_run[j]));
+        if (qi[j] < N) {
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.o) + ((int64_t)b * N + qi[j]) * p.o_cs + p.o_coff;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 t = {(bf16_t)(oacc[j][4 * g] * inv), (bf16_t)(oacc[j][4 * g + 1] * inv), (bf16_t)(oacc[j][4 * g + 2] * inv),
+                            (bf16_t)(oacc[j][4 * g + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(op + 8 * g + 4 * h) = t;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qoff, int koff, int voff, int B, int N,
@@ -179,7 +335,11 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
     if (dtype != SR_DTYPE_BF16 && dtype != SR_DTYPE_F32) return ctx->fail(SR_ERR_INVALID, "attention: dtype must be f32 or bf16");
     const int rec = ctx->prof_open(dtype == SR_DTYPE_BF16 ? "attn<bf16>" : "attn<f32>", 2.0 * B * (double)N * N * 40.0,
                                    (double)B * N * 80.0 * esz, st);
-    if (dtype == SR_DTYPE_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(256), 0, st, p);
+    static const bool v1 = getenv("SR355_ATTN_V1") != nullptr;     // A/B switch: first-generation kernel
+    if (dtype == SR_DTYPE_BF16 && !v1) {
+        const int64_t nwg = (int64_t)B * ((N + 255) / 256);
+        hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+    } else if (dtype == SR_DTYPE_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, st, p);
     ctx->prof_close(rec, st);
     SR_HIP(ctx, hipGetLastError());
