@@ -57,7 +57,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunk", type=int, default=147, help="patches per sr_forward call")
+    ap.add_argument("--chunk", type=int, default=1764, help="patches per sr_forward call (Keras predict chunking: result-invariant)")
+    ap.add_argument("--tiles-per-call", type=int, default=4, help="LR tiles whose patches share the generator launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass (no roofline object)")
     ap.add_argument("--no-attention", action="store_true", help="non-reference graph, kernel tuning only")
@@ -94,11 +95,17 @@ def main():
 
     def step():
         sums.zero_()
-        for t in range(TILES_PER_GPU):
-            sr, _ = model.super_resolve_image(lr[t], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk)
-            sums[0] += ctx.psnr(hr[t:t + 1], sr[None])[0].double()
-            sums[1] += ctx.ssim(hr[t:t + 1], sr[None])[0].double()
-            sums[2] += 1.0
+        g = max(1, args.tiles_per_call)
+        for t0 in range(0, TILES_PER_GPU, g):
+            ts = list(range(t0, min(t0 + g, TILES_PER_GPU)))
+            if len(ts) == 1:
+                srs = [model.super_resolve_image(lr[ts[0]], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk)[0]]
+            else:
+                srs, _ = model.super_resolve_images([lr[t] for t in ts], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk)
+            for t, sr in zip(ts, srs):
+                sums[0] += ctx.psnr(hr[t:t + 1], sr[None])[0].double()
+                sums[1] += ctx.ssim(hr[t:t + 1], sr[None])[0].double()
+                sums[2] += 1.0
         if world > 1:
             dist.all_reduce(sums)          # RCCL over xGMI: the path's only exchange step
         return sums
@@ -156,6 +163,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: ESRGAN-RRDB x4 (NB=23,G=32,2xSelfAttention) on 16 LR tiles 512x512 per GPU, "
                                    "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
                        "tiles_per_gpu": TILES_PER_GPU, "global_batch": world * TILES_PER_GPU, "patches_per_forward": args.chunk,
+                       "tiles_per_call": args.tiles_per_call,
                        "parallelism": f"dp{world} (tile shards, metric all-reduce only)"},
             "quality": {"mean_psnr_vs_hr_db": res[0] / res[2], "mean_ssim_vs_hr": res[1] / res[2], "note": "random-init weights"},
             "roofline": roof,
