@@ -69,11 +69,26 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if os.environ.get("SR355_ONE_DEVICE"):                     # rehearsal of the N>1 plumbing on a 1-GPU box: every rank drives cuda:0
+        local = 0
     torch.cuda.set_device(local)
     import torch.distributed as dist
+    backend = os.environ.get("SR355_DIST_BACKEND", "nccl")     # "gloo" only for that rehearsal
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+
+    def allreduce(t, op=dist.ReduceOp.SUM):
+        if world == 1:
+            return t
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+        return t
 
     from sr355 import Context
     from sr355.synth import make_pairs
@@ -106,8 +121,7 @@ def main():
                 sums[0] += ctx.psnr(hr[t:t + 1], sr[None])[0].double()
                 sums[1] += ctx.ssim(hr[t:t + 1], sr[None])[0].double()
                 sums[2] += 1.0
-        if world > 1:
-            dist.all_reduce(sums)          # RCCL over xGMI: the path's only exchange step
+        allreduce(sums)                    # RCCL over xGMI: the path's only exchange step
         return sums
 
     def fence():
@@ -135,8 +149,7 @@ def main():
         elapsed_prof = time.perf_counter() - t1
         prof = ctx.profile_end()
     et = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
-    if world > 1:
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+    allreduce(et, dist.ReduceOp.MAX)
     elapsed = float(et.item())
     res = out.cpu().numpy()
 
