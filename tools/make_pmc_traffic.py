@@ -1,0 +1,40 @@
+"""profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/probe_trunk.py.
+
+HBM bytes per launch = 2 * FETCH_SIZE * 1024 (gfx950: FETCH_SIZE reports half the bytes of a 16-B/lane stream,
+MI355X_MICROARCH.md section HBM) + WRITE_SIZE * 1024, averaged over the launches of each kernel template instance in
+the LAST forward of the probe.  Keys are bench.py's kernel names."""
+import csv, glob, json, sys
+
+NAMES = {"conv3_rows_kernel<1,": "conv_rows<bf16,k3,kg1,nt1>", "conv3_rows_kernel<2,": "conv_rows<bf16,k3,kg1,nt2>",
+         "conv3_rows_kernel<4,": "conv_rows<bf16,k3,kg1,nt4>"}
+
+
+def load(d, counter):
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    out = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            k = int(r["Dispatch_Id"])
+            out[k] = (r["Kernel_Name"], r["Grid_Size"], out.get(k, (None, None, 0.0))[2] + float(r["Counter_Value"]))
+    return out
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+last = max(fetch)
+n_per_fwd = int(sys.argv[3])                      # dispatches per forward of the probe
+agg = {}
+for k in range(last - n_per_fwd + 1, last + 1):
+    if k not in fetch or k not in write:
+        continue
+    name, grid, fv = fetch[k]
+    for pat, nm in NAMES.items():
+        if pat in name.replace(" ", "") or pat.replace(",", ", ") in name:
+            if int(grid) > 0 and nm == "conv_rows<bf16,k3,kg1,nt2>" or nm != "conv_rows<bf16,k3,kg1,nt2>":
+                a = agg.setdefault(nm, [0, 0.0])
+                a[0] += 1
+                a[1] += 2.0 * fv * 1024 + write[k][2] * 1024
+res = {nm: a[1] / a[0] for nm, a in agg.items()}
+res["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB -> B), separate rocprofv3 --pmc passes over tools/probe_trunk.py "
+                f"{sys.argv[4]} patches 48x48 (trunk convs only, no attention); averaged over the launches of one forward")
+json.dump(res, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
