@@ -11,6 +11,7 @@ Weak scaling: every rank owns 16 tiles.  value = SR output megapixels of all ran
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -59,6 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=1764, help="patches per sr_forward call (Keras predict chunking: result-invariant)")
     ap.add_argument("--tiles-per-call", type=int, default=4, help="LR tiles whose patches share the generator launches")
+    ap.add_argument("--streams", type=int, default=1, help="independent HIP streams (one generator instance each) the tiles are dealt to")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass (no roofline object)")
     ap.add_argument("--no-attention", action="store_true", help="non-reference graph, kernel tuning only")
@@ -96,10 +98,16 @@ def main():
     from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
 
     ctx = Context.get(local)
-    model = ESRGAN(compute_dtype="bf16")
-    model.setup_model(scale_factor=SCALE, growth_channels=G, num_rrdb_blocks=NB, use_attention=not args.no_attention)
-    weights = init_weights(model.generator.layer_shapes(), seed=3000)
-    model.set_weights(weights)
+    models = []
+    for _ in range(max(1, args.streams)):
+        m_ = ESRGAN(compute_dtype="bf16")
+        m_.setup_model(scale_factor=SCALE, growth_channels=G, num_rrdb_blocks=NB, use_attention=not args.no_attention)
+        if not models:
+            weights = init_weights(m_.generator.layer_shapes(), seed=3000)
+        m_.set_weights(weights)
+        models.append(m_)
+    model = models[0]
+    streams = [torch.cuda.Stream(device=ctx.torch_device) for _ in models] if len(models) > 1 else [None]
 
     # synthetic 3D-print tiles, seeded per rank; 4 distinct tiles repeated to 16
     lr4, hr4 = make_pairs(4, LR, LR, SCALE, seed=42 + 2 + 1000 * rank)
@@ -111,12 +119,23 @@ def main():
     def step():
         sums.zero_()
         g = max(1, args.tiles_per_call)
-        for t0 in range(0, TILES_PER_GPU, g):
-            ts = list(range(t0, min(t0 + g, TILES_PER_GPU)))
-            if len(ts) == 1:
-                srs = [model.super_resolve_image(lr[ts[0]], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk)[0]]
-            else:
-                srs, _ = model.super_resolve_images([lr[t] for t in ts], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk)
+        groups = [list(range(t0, min(t0 + g, TILES_PER_GPU))) for t0 in range(0, TILES_PER_GPU, g)]
+        done = []
+        cur = torch.cuda.current_stream(ctx.torch_device)
+        for gi, ts in enumerate(groups):
+            mdl, st = models[gi % len(models)], streams[gi % len(models)]
+            if st is not None:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                if len(ts) == 1:
+                    srs = [mdl.super_resolve_image(lr[ts[0]], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk)[0]]
+                else:
+                    srs, _ = mdl.super_resolve_images([lr[t] for t in ts], patch_size_lr=PATCH, stride=STRIDE, batch_size=args.chunk,
+                                                      timed=False)
+            done.append((ts, srs, st))
+        for ts, srs, st in done:
+            if st is not None:
+                cur.wait_stream(st)
             for t, sr in zip(ts, srs):
                 sums[0] += ctx.psnr(hr[t:t + 1], sr[None])[0].double()
                 sums[1] += ctx.ssim(hr[t:t + 1], sr[None])[0].double()

@@ -92,14 +92,14 @@ class ESRGAN(DeviceModelMixin):
                                      in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5)
         return (sr.cpu().numpy() if is_np else sr), metrics
 
-    def super_resolve_images(self, lr_imgs, patch_size_lr=48, stride=24, batch_size=16):
+    def super_resolve_images(self, lr_imgs, patch_size_lr=48, stride=24, batch_size=16, timed=True):
         """super_resolve_image over several equally sized LR images in one go (not in the reference; same results image
         by image, their patches just share the generator launches).  Returns ([sr_img...], inference_metrics)."""
         if not self.trained:
             raise RuntimeError("Model has not been trained or loaded.")
         conv = [P.as_device_image(self.ctx, im) for im in lr_imgs]
         srs, metrics = P.patchwise_sr_many(self.generator, [c[0] for c in conv], patch_size_lr, stride, self.scale_factor,
-                                           chunk=max(int(batch_size), 147), in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5)
+                                           chunk=max(int(batch_size), 147), in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5, timed=timed)
         return [sr.cpu().numpy() if c[1] else sr for sr, c in zip(srs, conv)], metrics
 
     def save(self, directory, timestamp):

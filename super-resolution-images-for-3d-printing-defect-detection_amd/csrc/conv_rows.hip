@@ -227,40 +227,67 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
             const int r = r0 + rr;
             if (r < rows) {                                  // wave-uniform
                 const int oy = oyw + r;
+                f32x4 v[NB16];
 #pragma unroll
                 for (int n = 0; n < NB16; ++n) {
-                    f32x4 v = acc[r][n] + biasv[n];
+                    v[n] = acc[r][n] + biasv[n];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope) * alpha;
+                    for (int e = 0; e < 4; ++e) v[n][e] = fmaxf(v[n][e], v[n][e] * slope) * alpha;
                     if (has1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += beta1 * (float)k1[rr][n][e];
+                        for (int e = 0; e < 4; ++e) v[n][e] += beta1 * (float)k1[rr][n][e];
                     }
                     if (has2) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += beta2 * (float)k2[rr][n][e];
+                        for (int e = 0; e < 4; ++e) v[n][e] += beta2 * (float)k2[rr][n][e];
                     }
                     if (clip) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+                        for (int e = 0; e < 4; ++e) v[n][e] = fminf(fmaxf(v[n][e], 0.f), 1.f);
                     }
-                    int64_t rowbase;    // wave-uniform element index of the output row start
-                    int loff;           // per-lane offset inside the row
+                }
+                // wave-uniform element index of the output row start / per-lane offset inside the row, per cout block
+                auto addr = [&](int n, int cadd, int64_t& rowbase, int& loff) {
                     if (rr_ <= 1) {
                         rowbase = (img_pix + (int64_t)oy * W) * p.out_cs;
-                        loff = ox * (int)p.out_cs + p.out_coff + c0[n];
+                        loff = ox * (int)p.out_cs + p.out_coff + (ct * NB16 + n) * 16 + cadd;
                     } else {            // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c; Cd % 16 == 0 -> (i,j) uniform per block
                         const int blk = (ct * NB16 + n) * 16, sub = blk / Cd, cb = blk - sub * Cd;
                         const int i = sub / rr_, j = sub - i * rr_;
                         rowbase = (img_pix * rr_ * rr_ + ((int64_t)oy * rr_ + i) * ((int64_t)W * rr_)) * p.out_cs;
-                        loff = (ox * rr_ + j) * (int)p.out_cs + p.out_coff + cb + 4 * q;
+                        loff = (ox * rr_ + j) * (int)p.out_cs + p.out_coff + cb + cadd;
                     }
-                    if (col_ok && c0[n] < p.Cout) {
-                        if (of32) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + rowbase + loff) = v;
-                        } else {
-                            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + rowbase + loff) = o;
+                };
+                const bool pair_ok = NB16 >= 2 && !of32 && (rr_ <= 1 || (Cd & 31) == 0) && (p.Cout & 31) == 0;
+                if (pair_ok) {
+                    // 16-byte stores: lanes q and q^1 (16 lanes apart) trade halves with v_permlane16_swap, so an even-q lane
+                    // ends up with 8 consecutive couts of the even block and the odd-q lane with 8 of the odd block.
+#pragma unroll
+                    for (int n = 0; n + 1 < NB16; n += 2) {
+                        bf16x4 a = {(bf16_t)v[n][0], (bf16_t)v[n][1], (bf16_t)v[n][2], (bf16_t)v[n][3]};
+                        bf16x4 c = {(bf16_t)v[n + 1][0], (bf16_t)v[n + 1][1], (bf16_t)v[n + 1][2], (bf16_t)v[n + 1][3]};
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        u32x2 au = __builtin_bit_cast(u32x2, a), cu = __builtin_bit_cast(u32x2, c);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 o = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+                        int64_t rowbase; int loff;
+                        addr(n + (q & 1), 4 * (q & ~1), rowbase, loff);
+                        if (col_ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + rowbase + loff) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NB16; ++n) {
+                        int64_t rowbase; int loff;
+                        addr(n, 4 * q, rowbase, loff);
+                        if (col_ok && c0[n] < p.Cout) {
+                            if (of32) {
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + rowbase + loff) = v[n];
+                            } else {
+                                bf16x4 o = {(bf16_t)v[n][0], (bf16_t)v[n][1], (bf16_t)v[n][2], (bf16_t)v[n][3]};
+                                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + rowbase + loff) = o;
+                            }
                         }
                     }
                 }
