@@ -59,10 +59,14 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
         const int qn = total >> 3, rn = total & 7;
         t = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + k;
     }
-    const int tx = t % p.tilesX; t /= p.tilesX;
+    // the cout tiles of one spatial tile are neighbours in the order (same XCD, same time): the input they all stage
+    // is fetched from HBM once and served from L2 to the others
+    const int nct = p.tilesX >> 16;                          // packed by the launcher: tilesX = (nct << 16) | tiles in x
+    const int tilesX = p.tilesX & 0xffff;
+    const int ct = t % nct; t /= nct;
+    const int tx = t % tilesX; t /= tilesX;
     const int ty = t % p.tilesY;
     const int b = t / p.tilesY;
-    const int ct = blockIdx.y;
     const int y0 = ty * TH, x0 = tx * TW;
     const int H = p.H, W = p.W, in_cs = (int)p.in_cs;
     const bf16_t* inb = reinterpret_cast<const bf16_t*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;   // wave-uniform
@@ -304,9 +308,13 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     constexpr int R = NB16 == 4 ? 4 : 6;
     constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024;
     ConvParams p = p0;
-    p.tilesX = (p.W + 15) / 16;
+    const int tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 4 * R - 1) / (4 * R);
-    dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
+    if (tilesX > 0xffff || nct > 0x7fff) return ctx->fail(SR_ERR_INVALID, "conv_rows: image too wide / too many cout tiles");
+    const int64_t nwg = (int64_t)tilesX * p.tilesY * p.B * nct;
+    if (nwg >= (1ll << 31)) return ctx->fail(SR_ERR_INVALID, "conv_rows: too many workgroups for one launch");
+    p.tilesX = (nct << 16) | tilesX;
+    dim3 grid((unsigned)nwg, 1u);
     if (p.dbg) {   // diagnostic stamped variant
         auto kd = conv3_rows_kernel<NB16, R, true>;
         SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
