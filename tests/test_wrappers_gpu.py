@@ -102,6 +102,10 @@ def test_esrgan_wrapper(ctx, dtype, tol):
     # device-tensor in -> device-tensor out, same numbers
     sr_t, _ = m.super_resolve_image(ctx.to_device(lr[0]), patch_size_lr=24, stride=12)
     assert isinstance(sr_t, torch.Tensor) and np.array_equal(sr_t.cpu().numpy(), sr)
+    # several images per generator call: identical results, image by image
+    many, _ = m.super_resolve_images([lr[0], lr[0][::-1].copy()], patch_size_lr=24, stride=12)
+    assert np.array_equal(many[0], sr)
+    assert np.array_equal(many[1], m.super_resolve_image(lr[0][::-1].copy(), patch_size_lr=24, stride=12)[0])
     ev = m.evaluate([(lr[:1, :24, :24] * 2 - 1, hr[:1, :48, :48] * 2 - 1)])
     assert set(ev) == {"avg_psnr", "avg_ssim", "avg_g_loss"}
 
