@@ -170,8 +170,9 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // bf16 production kernel.  Same formulation; tuned for the binding resource (VALU / v_exp_f32 issue):
-//   * a wave owns TWO 32-query blocks (64 queries): every key fragment load, V^T fragment read and
-//     barrier is shared by both; workgroup = 256 queries, key tile = 128 keys per barrier;
+//   * QB 32-query blocks per wave (template; QB = 1 is the default: 86 VGPRs -> 5 waves/SIMD measured 10 % faster than
+//     QB = 2, which shares every key/V^T fragment between two blocks but drops to 2 waves/SIMD); key tile = 128 keys
+//     per barrier;
 //   * softmax in the exp2 domain: p = exp2(s*log2e - m'), one fma + one v_exp_f32 per score;
 //   * the O/l rescale runs only when some lane's running max actually grew (wave-uniform vote), which
 //     after the first few key tiles is rare; the result is bit-identical to rescaling every tile
@@ -182,32 +183,36 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnParams p) {
 constexpr int KT2 = 128;                       // keys per barrier
 constexpr int PITCH2 = KT2 * 2 + 8;            // bytes per V^T row: 66 dwords -> conflict-free ds_read_b64
 
+template <int QB>
 __global__ void __launch_bounds__(256) attn_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char vt[32 * PITCH2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int N = p.N;
-    const int nqt = (N + 255) / 256;
+    constexpr int QW = 64 * QB * 2;   // queries per workgroup (4 waves x QB blocks of 32)
+    const int nqt = (N + QW - 1) / QW;
     const int b = blockIdx.x / nqt, qt = blockIdx.x - b * nqt;
     const bf16_t* base = reinterpret_cast<const bf16_t*>(p.qkv) + (int64_t)b * N * p.cs;
     const int cs = (int)p.cs;
     const float LOG2E = 1.4426950408889634f;
 
-    int qi[2];
-    bf16x8 qb[2];
+    int qi[QB];
+    bf16x8 qb[QB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        qi[j] = qt * 256 + wave * 64 + j * 32 + r;
+    for (int j = 0; j < QB; ++j) {
+        qi[j] = qt * QW + wave * (32 * QB) + j * 32 + r;
         const int qc = qi[j] < N ? qi[j] : N - 1;
         bf16x8 z = {};
         qb[j] = z;
         if (h == 0) qb[j] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qc * cs + p.qoff);
     }
-    f32x16 oacc[2];
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    f32x16 oacc[QB];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < QB; ++j) {
+        m_run[j] = -INFINITY; l_run[j] = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
+    }
 
     const int kp = tid >> 2, oct = tid & 3;    // V staging: key pair, 8-channel octet
     auto load_k = [&](int kb) {
@@ -230,10 +235,10 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(AttnParams p) {
     auto tile = [&](const bf16x8 kf, const int sub, const int kb, auto ragged_tag) {
         constexpr bool RAGGED = sizeof(ragged_tag) > 1;
         // phase A (both query blocks, no control flow in between): scores and their column maxima
-        f32x16 s[2];
-        float mx[2];
+        f32x16 s[QB];
+        float mx[QB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < QB; ++j) {
             s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb[j], zero16, 0, 0, 0);
             if constexpr (RAGGED) {
 #pragma unroll
@@ -247,9 +252,12 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(AttnParams p) {
             mx[j] = hmax(m) * LOG2E;
         }
         // phase B: one wave-uniform vote for both blocks; rescale only when a running max grew
-        if (__any(mx[0] > m_run[0] || mx[1] > m_run[1])) {
+        bool grew = false;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < QB; ++j) grew = grew || mx[j] > m_run[j];
+        if (__any(grew)) {
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
                 const float m_new = fmaxf(m_run[j], mx[j]);
                 const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);   // exp2(-inf) = 0 first; exp2(0) = 1 exactly
                 l_run[j] *= alpha;
@@ -260,7 +268,7 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(AttnParams p) {
         }
         // phase C (both blocks interleavable): probabilities, row sums, O^T += V^T . P^T
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < QB; ++j) {
             const float nm = -m_run[j];
             float psum = 0.f;
 #pragma unroll
@@ -274,7 +282,7 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(AttnParams p) {
             const bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + 16);
             const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < QB; ++j) {
                 bf16x8 pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[j][8 * ks + e];
@@ -308,7 +316,7 @@ __global__ void __launch_bounds__(256) attn_bf16_kernel(AttnParams p) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < QB; ++j) {
         const float inv = 1.f / (l_run[j] + xhalf(l_run[j]));
         if (qi[j] < N) {
             bf16_t* op = reinterpret_cast<bf16_t*>(p.o) + ((int64_t)b * N + qi[j]) * p.o_cs + p.o_coff;
@@ -337,8 +345,14 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
                                    (double)B * N * 80.0 * esz, st);
     static const bool v1 = getenv("SR355_ATTN_V1") != nullptr;     // A/B switch: first-generation kernel
     if (dtype == SR_DTYPE_BF16 && !v1) {
-        const int64_t nwg = (int64_t)B * ((N + 255) / 256);
-        hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        static const int qb = getenv("SR355_ATTN_QB") ? atoi(getenv("SR355_ATTN_QB")) : 1;   // 1 query block per wave: 86 VGPRs, 5 waves/SIMD (measured faster than 2)
+        if (qb == 1) {
+            const int64_t nwg = (int64_t)B * ((N + 127) / 128);
+            hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        } else {
+            const int64_t nwg = (int64_t)B * ((N + 255) / 256);
+            hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        }
     } else if (dtype == SR_DTYPE_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, st, p);
     ctx->prof_close(rec, st);
