@@ -88,3 +88,14 @@ def majority_vote(probs):
     tied = np.where(votes == votes.max())[0]
     win = int(tied[0]) if len(tied) == 1 else int(tied[np.argmax(probs.mean(axis=0)[tied])])
     return win, float(probs[:, win].mean())
+
+
+def sr_then_classify(sr_model, classifier, lr_img, sr_kwargs=None, patch_size=96, stride=48, batch_size=32):
+    """The (missing) defect_detection_pipeline notebook's inner loop, reconstructed from the helpers written for it
+    (SURVEY.md 3.5): LR image -> `super_resolve_image` -> `classify_defects_method` on the SR output.  The SR image
+    stays on the device between the two models.  Returns (sr_img device tensor, inference_metrics, class, confidence)."""
+    ctx = sr_model.ctx
+    lr, _ = as_device_image(ctx, lr_img)
+    sr, metrics = sr_model.super_resolve_image(lr, **(sr_kwargs or {}))
+    cls, conf = classifier.classify_defects_method(sr, patch_size=patch_size, stride=stride, batch_size=batch_size)
+    return sr, metrics, cls, conf

@@ -121,3 +121,41 @@ def test_vgg16_wrapper(ctx):
     cls, conf = m.classify_defects_method(img, patch_size=96, stride=48)
     rcls, rconf = M.classify_defects(img, m.weights, 96, 48, dtype=np.float64)
     assert cls == rcls and abs(conf - rconf) <= 1e-4
+
+
+def test_sr_then_classify_pipeline(ctx):
+    """BASELINE configs[4] in miniature: x4 ESRGAN super-resolution, then the VGG16 patch vote on the SR image, device-resident."""
+    from sr355.pipeline import sr_then_classify
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    from SRModels.defect_detection_models.VGG16_model import FineTunedVGG16
+    g = ESRGAN(compute_dtype="f32")
+    g.setup_model(scale_factor=4, growth_channels=8, num_rrdb_blocks=1)
+    g.set_weights(g.weights)
+    c = FineTunedVGG16()
+    c.setup_model(input_shape=(96, 96, 3), num_classes=2)
+    lr, _ = make_pairs(1, 40, 36, 4, seed=8)
+    sr, met, cls, conf = sr_then_classify(g, c, lr[0], sr_kwargs=dict(patch_size_lr=24, stride=12))
+    ref_sr = M.esrgan_super_resolve(lr[0], g.weights, 4, 24, 12, num_rrdb=1, dtype=np.float64)
+    assert tuple(sr.shape) == (160, 144, 3) and np.max(np.abs(sr.cpu().numpy() - ref_sr)) <= 1e-5
+    rcls, rconf = M.classify_defects(ref_sr.astype(np.float32), c.weights, 96, 48, dtype=np.float64)
+    assert cls == rcls and abs(conf - rconf) <= 1e-4 and "time_sec" in met
+
+
+def test_whole_image_attention_sampled_rows(ctx):
+    """SelfAttention on a whole 128x128 feature map (N = 16384: the score matrix would be 2 GB in fp64 and is never
+    materialised on either side): the HIP streaming-softmax kernel against the fp64 streaming oracle on sampled query rows."""
+    from sr355.weights import init_weights
+    rng = np.random.default_rng(21)
+    H = W = 128
+    x = (0.5 * rng.standard_normal((1, H, W, 64))).astype(np.float32)
+    w = init_weights(M.self_attention_layers("sa"), seed=5)
+    y = ctx.self_attention(ctx.to_device(x), *w["sa_f"], *w["sa_g"], *w["sa_h"], *w["sa_v"]).cpu().numpy()
+    X = x.reshape(-1, 64).astype(np.float64)
+    f = X @ w["sa_f"][0][0, 0] + w["sa_f"][1]
+    g = X @ w["sa_g"][0][0, 0] + w["sa_g"][1]
+    h = X @ w["sa_h"][0][0, 0] + w["sa_h"][1]
+    rows = rng.choice(H * W, size=64, replace=False)
+    o = O.attention_rows_streaming(g[rows], f, h)
+    ref = X[rows] + o @ w["sa_v"][0][0, 0] + w["sa_v"][1]
+    got = y.reshape(-1, 64)[rows]
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 2e-5
