@@ -86,13 +86,17 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     bf16x8 pre[NINT];
     f32x4 wpre[NWT];
     const char* wbase = p.w + (int64_t)ct * p.nchunks * (int64_t)(WUNITS * 16);
+    // The prefetch loads are inline asm on purpose: hipcc otherwise waits for them (s_waitcnt vmcnt) right after issue --
+    // it touches their destination registers early -- and the next chunk's HBM latency is no longer hidden under this
+    // chunk's MFMAs (seen in the .s of the plain-C++ version: vmcnt(3..0) between the loads and the first MFMA).  An asm
+    // load is invisible to the compiler's wait bookkeeping; land_all() below is the one explicit wait, placed right before
+    // the registers are written to LDS, and it names every destination so nothing is scheduled across it.
     auto issue = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NINT; ++i) {
             const int so = soff[i];
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (so >= 0 ? so + chunk * 32 : 0));   // always a valid address
-            bf16x8 z = {};
-            pre[i] = so >= 0 ? v : z;
+            const bf16_t* ptr = inb + (so >= 0 ? so + chunk * 32 : 0);   // always a valid address; zero-select happens after landing
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[i]) : "v"(ptr) : "memory");
         }
     };
     auto issue_w = [&](int chunk) {
@@ -100,8 +104,16 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int u = tid + 256 * i;
-            wpre[i] = *reinterpret_cast<const f32x4*>(wsrc + (u < WUNITS ? u : 0) * 16);
+            const char* ptr = wsrc + (u < WUNITS ? u : 0) * 16;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wpre[i]) : "v"(ptr) : "memory");
         }
+    };
+    auto land_all = [&]() {   // wait for every asm load in flight; "+v" on each destination orders all their uses behind the wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NINT; ++i) asm volatile("" : "+v"(pre[i]));
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) asm volatile("" : "+v"(wpre[i]));
     };
     auto write_w = [&]() {
 #pragma unroll
@@ -135,10 +147,14 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         __syncthreads();
         if (chunk < 6) STAMP_AT(2 + 2 * chunk);
+        if (!WPRE) issue_w(chunk);     // all loads in flight together, one exposed latency per chunk
+        land_all();
 #pragma unroll
         for (int i = 0; i < NINT; ++i)
-            if (doff[i] >= 0) *reinterpret_cast<bf16x8*>(lin + doff[i]) = pre[i];
-        if (!WPRE) issue_w(chunk);     // all loads in flight together, one exposed latency per chunk
+            if (doff[i] >= 0) {
+                bf16x8 z = {};
+                *reinterpret_cast<bf16x8*>(lin + doff[i]) = soff[i] >= 0 ? pre[i] : z;
+            }
         write_w();
         __syncthreads();
         if (chunk < 6) STAMP_AT(3 + 2 * chunk);
