@@ -441,6 +441,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.out_f32 = (ep.out_f32 || w.dtype == SR_DTYPE_F32) ? 1 : 0;
     p.s1 = static_cast<const char*>(ep.skip1.p); p.s1_cs = ep.skip1.cs; p.s1_coff = ep.skip1.coff; p.beta1 = ep.beta1;
     p.s2 = static_cast<const char*>(ep.skip2.p); p.s2_cs = ep.skip2.cs; p.s2_coff = ep.skip2.coff; p.beta2 = ep.beta2;
+    if (!p.s1 && p.s2) { p.s1 = p.s2; p.s1_cs = p.s2_cs; p.s1_coff = p.s2_coff; p.beta1 = p.beta2; p.s2 = nullptr; }   // a lone skip is skip 1
     p.alpha = ep.alpha; p.act = ep.act; p.clip = ep.clip01; p.r = r; p.Cd = w.Cout / (r * r);
     p.B = B; p.H = H; p.W = W; p.Cout = w.Cout; p.nchunks = w.nchunks; p.tilesX = p.tilesY = 0;
     p.dbg = ctx->stamp_buf;

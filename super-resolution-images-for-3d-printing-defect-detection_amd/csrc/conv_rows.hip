@@ -23,7 +23,7 @@
 // Prologue and epilogue are kept to a few hundred issue slots per wave (32-bit offsets from wave-uniform
 // 64-bit bases, branch-free activation, biases prefetched, skips loaded in bulk): in-kernel stamps showed
 // they, not the MFMAs, held the SIMDs in the first version.
-#include "conv_common.h"
+#include "conv_rows_epi.h"
 
 namespace {
 
@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lin = smem;
     char* lw = smem + LIN_BYTES;
+    float* lbias = reinterpret_cast<float*>(smem + LIN_BYTES + WUNITS * 16);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, px = lane & 15, q = lane >> 4;
     STAMP_AT(0);
@@ -125,10 +126,8 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
 
     issue(0);
     if (WPRE) issue_w(0);
-    // this lane's 4 biases per cout block, fetched now so the epilogue never waits on them
-    f32x4 biasv[NB16];
-#pragma unroll
-    for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(p.bias + (ct * NB16 + n) * 16 + 4 * q);
+    // the workgroup's biases wait in LDS for the epilogue: no global latency there, and no registers held across the loop
+    if (tid < NB16 * 16) lbias[tid] = p.bias[ct * NB16 * 16 + tid];
 
     f32x4 acc[R][NB16];
 #pragma unroll
@@ -190,130 +189,11 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     }
     STAMP_AT(14);
 
-    // ---- epilogue.  lane (px, q): pixel column px, couts 4q..4q+3 of each 16-block.
-    const int ox = x0 + px;
-    const int oyw = y0 + wave * R;                         // first output row of this wave (wave-uniform)
-    const int Cd = p.Cd, rr_ = p.r;
-    const bool fast = p.vec != 0 && (p.Cout & 3) == 0 && p.act != SR_ACT_TANH && (rr_ <= 1 || (Cd & 15) == 0);
-    if (!fast) {   // odd channel counts / unaligned views / tanh: generic per-element path (final RGB conv)
-        if (ox < W) {
+    // ---- epilogue (conv_rows_epi.h)
+    f32x4 biasv[NB16];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int oy = oyw + r;
-                if (oy >= H) continue;
-#pragma unroll
-                for (int n = 0; n < NB16; ++n) {
-                    const float a[4] = {acc[r][n][0], acc[r][n][1], acc[r][n][2], acc[r][n][3]};
-                    epilogue4<bf16_t>(p, b, oy, ox, (ct * NB16 + n) * 16 + 4 * q, a);
-                }
-            }
-        }
-        STAMP_AT(15);
-        return;
-    }
-    // fast path.  Activation is branch-free: max(v, slope*v) with slope 1 (linear), 0 (relu), 0.2 (leaky relu).
-    const float slope = p.act == SR_ACT_RELU ? 0.f : (p.act == SR_ACT_LRELU ? 0.2f : 1.f);
-    const float alpha = p.alpha, beta1 = p.beta1, beta2 = p.beta2;
-    const bool has1 = p.s1 != nullptr, has2 = p.s2 != nullptr, clip = p.clip != 0, of32 = p.out_f32 != 0;
-    const int rows = min(R, H - oyw);                     // wave-uniform count of live rows (<= 0: nothing to do)
-    const bool col_ok = ox < W;
-    const int64_t img_pix = (int64_t)b * H * W;           // wave-uniform
-    int c0[NB16];                                         // first cout of this lane in each block
-#pragma unroll
-    for (int n = 0; n < NB16; ++n) c0[n] = (ct * NB16 + n) * 16 + 4 * q;
-    constexpr int RG = NB16 == 4 ? 2 : R;
-#pragma unroll
-    for (int r0 = 0; r0 < R; r0 += RG) {
-        bf16x4 k1[RG][NB16], k2[RG][NB16];
-        if (has1 || has2) {
-#pragma unroll
-            for (int rr = 0; rr < RG; ++rr) {
-                const int r = r0 + rr;
-                const bool ok = r < rows && col_ok;
-                const int64_t rowpix = img_pix + (int64_t)(r < rows ? oyw + r : 0) * W;   // dead rows read row 0: valid memory
-                const int oxc = ok ? ox : 0;
-#pragma unroll
-                for (int n = 0; n < NB16; ++n) {
-                    const int cc = min(c0[n], p.Cout - 4);
-                    if (has1) k1[rr][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s1) + rowpix * p.s1_cs +
-                                                                          (oxc * (int)p.s1_cs + p.s1_coff + cc));
-                    if (has2) k2[rr][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s2) + rowpix * p.s2_cs +
-                                                                          (oxc * (int)p.s2_cs + p.s2_coff + cc));
-                }
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < RG; ++rr) {
-            const int r = r0 + rr;
-            if (r < rows) {                                  // wave-uniform
-                const int oy = oyw + r;
-                f32x4 v[NB16];
-#pragma unroll
-                for (int n = 0; n < NB16; ++n) {
-                    v[n] = acc[r][n] + biasv[n];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[n][e] = fmaxf(v[n][e], v[n][e] * slope) * alpha;
-                    if (has1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[n][e] += beta1 * (float)k1[rr][n][e];
-                    }
-                    if (has2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[n][e] += beta2 * (float)k2[rr][n][e];
-                    }
-                    if (clip) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[n][e] = fminf(fmaxf(v[n][e], 0.f), 1.f);
-                    }
-                }
-                // wave-uniform element index of the output row start / per-lane offset inside the row, per cout block
-                auto addr = [&](int n, int cadd, int64_t& rowbase, int& loff) {
-                    if (rr_ <= 1) {
-                        rowbase = (img_pix + (int64_t)oy * W) * p.out_cs;
-                        loff = ox * (int)p.out_cs + p.out_coff + (ct * NB16 + n) * 16 + cadd;
-                    } else {            // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c; Cd % 16 == 0 -> (i,j) uniform per block
-                        const int blk = (ct * NB16 + n) * 16, sub = blk / Cd, cb = blk - sub * Cd;
-                        const int i = sub / rr_, j = sub - i * rr_;
-                        rowbase = (img_pix * rr_ * rr_ + ((int64_t)oy * rr_ + i) * ((int64_t)W * rr_)) * p.out_cs;
-                        loff = (ox * rr_ + j) * (int)p.out_cs + p.out_coff + cb + cadd;
-                    }
-                };
-                const bool pair_ok = NB16 >= 2 && !of32 && (rr_ <= 1 || (Cd & 31) == 0) && (p.Cout & 31) == 0;
-                if (pair_ok) {
-                    // 16-byte stores: lanes q and q^1 (16 lanes apart) trade halves with v_permlane16_swap, so an even-q lane
-                    // ends up with 8 consecutive couts of the even block and the odd-q lane with 8 of the odd block.
-#pragma unroll
-                    for (int n = 0; n + 1 < NB16; n += 2) {
-                        bf16x4 a = {(bf16_t)v[n][0], (bf16_t)v[n][1], (bf16_t)v[n][2], (bf16_t)v[n][3]};
-                        bf16x4 c = {(bf16_t)v[n + 1][0], (bf16_t)v[n + 1][1], (bf16_t)v[n + 1][2], (bf16_t)v[n + 1][3]};
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        u32x2 au = __builtin_bit_cast(u32x2, a), cu = __builtin_bit_cast(u32x2, c);
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 o = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
-                        int64_t rowbase; int loff;
-                        addr(n + (q & 1), 4 * (q & ~1), rowbase, loff);
-                        if (col_ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + rowbase + loff) = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NB16; ++n) {
-                        int64_t rowbase; int loff;
-                        addr(n, 4 * q, rowbase, loff);
-                        if (col_ok && c0[n] < p.Cout) {
-                            if (of32) {
-                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + rowbase + loff) = v[n];
-                            } else {
-                                bf16x4 o = {(bf16_t)v[n][0], (bf16_t)v[n][1], (bf16_t)v[n][2], (bf16_t)v[n][3]};
-                                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + rowbase + loff) = o;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
+    for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
+    rows_epilogue<NB16, R>(p, acc, biasv, b, y0, x0, ct, wave, px, q);
     STAMP_AT(15);
 }
 
@@ -322,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
 template <int NB16>
 int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     constexpr int R = NB16 == 4 ? 4 : 6;
-    constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024;
+    constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024 + NB16 * 64;
     ConvParams p = p0;
     const int tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 4 * R - 1) / (4 * R);
