@@ -348,8 +348,7 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
     if (KS == 5 && !(Cin <= E)) w.NT = 1;   // 25 taps of weights: keep the LDS stage small
     const int nct = nb / w.NT, ntap = KS * KS;
     w.thin = Cin <= E;
-    static const bool force_v1 = getenv("SR355_CONV_V1") != nullptr;
-    w.rows = (dtype == SR_DTYPE_BF16 && KS == 3 && !w.thin && !force_v1) ? 1 : 0;
+    w.rows = (dtype == SR_DTYPE_BF16 && KS == 3 && !w.thin) ? 1 : 0;
     if (!w.thin && KS == 9) return ctx->fail(SR_ERR_INVALID, "conv: 9x9 supported for <= one 16-byte channel slice only");
     std::vector<char> host;
     auto put = [&](size_t idx, float v) {
