@@ -449,6 +449,13 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);
     if (p.s2) vec = vec && (p.s2_cs % 4 == 0) && (p.s2_coff % 4 == 0) && ((uintptr_t)p.s2 % (4 * esz) == 0);
     p.vec = vec ? 1 : 0;
+    // a dense block adds its own input back: when a skip is exactly input channels [0, Cout) of this conv, conv_rows folds it in
+    // from the LDS image of those channels while they are staged, instead of reading it again in the epilogue (conv_rows.hip)
+    p.skip_lds = 0; p.skip_scale = 0.f;
+    if (w.rows && w.NT == 4 && w.Cout % 16 == 0 && w.Cin >= w.Cout && ep.act == SR_ACT_LINEAR && ep.alpha != 0.f && r == 1 && vec) {
+        if (p.s2 && p.s2 == p.in && p.s2_cs == p.in_cs && p.s2_coff == p.in_coff) { p.skip_lds = 2; p.skip_scale = p.beta2 / p.alpha; }
+        else if (p.s1 && p.s1 == p.in && p.s1_cs == p.in_cs && p.s1_coff == p.in_coff) { p.skip_lds = 1; p.skip_scale = p.beta1 / p.alpha; }
+    }
     const int nct = w.CoutP / 32 / w.NT;
     int rec = -1;
     if (ctx->prof) {

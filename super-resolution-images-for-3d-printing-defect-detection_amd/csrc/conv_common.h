@@ -15,6 +15,8 @@ struct ConvParams {
     int nchunks;        // wide: Cin chunks; thin: number of k-groups (taps pairs)
     int tilesX, tilesY;
     int vec;            // epilogue may use 4-element vector loads/stores
+    int skip_lds;       // conv_rows: skip 1 / 2 (value 1 / 2) is input channels [0, Cout) of this conv -- folded in from LDS
+    float skip_scale;   // its beta / alpha
     unsigned long long* dbg;   // diagnostic builds only: 16 s_memtime stamps per workgroup (sr_debug_set_stamp_buffer)
 };
 

@@ -10,8 +10,13 @@
 //   loop  = for each 32-channel chunk, for kx in 0..2: hold the 3 (ky) x NB16 weight fragments in
 //           registers, walk the R+2 input rows of the strip once; the fragment of input row yi feeds
 //           output rows yi, yi-1, yi-2 (ky = 0, 1, 2).
-//   LDS reads per 16-cycle MFMA: (R+2)/(3*R*NB16) pixel + 1/R weight fragments (0.39 at R=6, Cout=32;
+//   LDS reads per 16-cycle MFMA: (R+2)/(3*R*NB16) pixel + 1/R weight fragments (0.5 at R=4, Cout=32;
 //   the old kernel: 1.33 per 32-cycle MFMA).
+//
+// Tile sizes are set by occupancy, not by MFMA efficiency: these layers stream their input from HBM once and run
+// against the memory system, so what pays is workgroups in flight per CU.  16x16 tiles (R=4) at 32 or 16
+// couts per workgroup: 39 KB of LDS, <= 128 VGPRs -> 4 workgroups/CU; 12x16 tiles (R=3) at 64 couts: 52 KB, <= 168 VGPRs
+// -> 3 workgroups/CU.  (24x16 tiles at 2-3 workgroups/CU had fewer LDS reads per MFMA and were 5-7 % slower.)
 //
 // LDS image of the input halo tile: pixel-major, 64 B per pixel per chunk, no padding; 16-byte slice q
 // of pixel index t (t = row*18 + col) sits at t*64 + ((q*16) ^ ((t & 4) << 3)).  With that XOR the 16
@@ -36,7 +41,7 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
 #define STAMP_AT(i) do { if (STAMP && tid == 0) p.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <int NB16, int R, bool STAMP>
-__global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
+__global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(ConvParams p) {
     constexpr int TH = 4 * R, TW = 16, PH = TH + 2, PW = TW + 2;
     constexpr int NPIX = PH * PW;
     constexpr int NIN = NPIX * 4;                 // 16-byte units per chunk
@@ -44,7 +49,7 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     constexpr int LIN_BYTES = NPIX * 64;
     constexpr int WUNITS = 9 * NB16 * 64;         // 16-byte units of weights per chunk
     constexpr int NWT = (WUNITS + 255) / 256;     // weight units per thread
-    constexpr bool WPRE = NB16 <= 2;              // prefetch next chunk's weights into registers when they fit
+    constexpr bool WPRE = NB16 <= 1;              // prefetch next chunk's weights into registers when they fit the occupancy target's VGPR budget
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lin = smem;
     char* lw = smem + LIN_BYTES;
@@ -84,6 +89,14 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
         doff[i] = live ? pix * 64 + ((sl * 16) ^ ((pix & 4) << 3)) : -1;
         soff[i] = inside ? (gy * W + gx) * in_cs + sl * 8 : -1;
     }
+    // Skip from LDS (p.skip_lds = 1 or 2): that skip tensor IS input channels [0, Cout) of this conv (a dense block adding its
+    // own input back; linear activation, host-checked).  Cout block g then needs x channels 16g..16g+15 at the centre pixel,
+    // which sit in the LDS image while chunk g/2 is staged: they are folded into the accumulators right there,
+    //   alpha*(acc + b) + beta*x == alpha*((acc + (beta/alpha)*x) + b)   (up to fp32 rounding),
+    // and the epilogue no longer reads that skip from HBM.
+    const int nch = p.nchunks;
+    constexpr bool SKIP_LDS_OK = NB16 == 4;      // only the 64-couts-per-workgroup variant carries the code (register budget)
+    const bool skip_lds = SKIP_LDS_OK && p.skip_lds != 0;
     bf16x8 pre[NINT];
     f32x4 wpre[NWT];
     const char* wbase = p.w + (int64_t)ct * p.nchunks * (int64_t)(WUNITS * 16);
@@ -143,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     };
     STAMP_AT(1);
 
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    for (int chunk = 0; chunk < nch; ++chunk) {
         __syncthreads();
         if (chunk < 6) STAMP_AT(2 + 2 * chunk);
         if (!WPRE) issue_w(chunk);     // all loads in flight together, one exposed latency per chunk
@@ -157,7 +170,7 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
         write_w();
         __syncthreads();
         if (chunk < 6) STAMP_AT(3 + 2 * chunk);
-        if (chunk + 1 < p.nchunks) {
+        if (chunk + 1 < nch) {
             issue(chunk + 1);
             if (WPRE) issue_w(chunk + 1);
         }
@@ -186,6 +199,22 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
                 }
             }
         }
+        if constexpr (SKIP_LDS_OK) if (skip_lds) {
+            const float sc = p.skip_scale;
+#pragma unroll
+            for (int n = 0; n < NB16; ++n) {
+                const int g = ct * NB16 + n;                                     // wave-uniform
+                if ((g >> 1) != chunk) continue;
+                const int slice = (g & 1) * 2 + (q >> 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int tt = (wave * R + r + 1) * PW + px + 1;             // centre pixel of output (row r, column px)
+                    const bf16x4 xk = *reinterpret_cast<const bf16x4*>(lin + tt * 64 + ((slice * 16) ^ ((tt & 4) << 3)) + (q & 1) * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[r][n][e] += sc * (float)xk[e];
+                }
+            }
+        }
     }
     STAMP_AT(14);
 
@@ -193,15 +222,23 @@ __global__ void __launch_bounds__(256, 2) conv3_rows_kernel(ConvParams p) {
     f32x4 biasv[NB16];
 #pragma unroll
     for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
+    if constexpr (SKIP_LDS_OK) if (skip_lds) {
+        ConvParams pe = p;                                                  // the epilogue sees only the other skip, as skip 1
+        if (p.skip_lds == 1) { pe.s1 = p.s2; pe.s1_cs = p.s2_cs; pe.s1_coff = p.s2_coff; pe.beta1 = p.beta2; }
+        pe.s2 = nullptr;
+        rows_epilogue<NB16, R>(pe, acc, biasv, b, y0, x0, ct, wave, px, q);
+        STAMP_AT(15);
+        return;
+    }
     rows_epilogue<NB16, R>(p, acc, biasv, b, y0, x0, ct, wave, px, q);
     STAMP_AT(15);
 }
 
-// rows per wave: 24 x 16 output tiles (16 x 16 for 64 couts per workgroup, to stay inside 256 VGPRs without spills);
+// rows per wave: 16 x 16 output tiles, 12 x 16 for 64 couts per workgroup (see the occupancy note in the header);
 // 48/96/192-pixel patches tile exactly either way
 template <int NB16>
 int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
-    constexpr int R = NB16 == 4 ? 4 : 6;
+    constexpr int R = NB16 == 4 ? 3 : 4;
     constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024 + NB16 * 64;
     ConvParams p = p0;
     const int tilesX = (p.W + 15) / 16;

@@ -77,6 +77,34 @@ def test_conv2d_epilogue_skips_clip(ctx, dtype):
     assert rel_l2(got, ref) <= (1e-5 if dtype == "f32" else 1e-2)
 
 
+@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("hw", [(26, 18), (48, 48), (7, 5)])
+def test_conv2d_skip_is_own_input(ctx, hw, which):
+    """Dense-block tail: y = alpha*conv(x) + beta*x (+ another skip).  When a skip tensor IS the conv's first 64 input channels the
+    bf16 3x3 kernel takes it from its LDS tile instead of reading it again (conv_rows.hip "skip from LDS"); same numbers either way."""
+    rng = np.random.default_rng(11 + which)
+    H, W = hw
+    x = round_to_bf16(rng.standard_normal((3, H, W, 64)).astype(np.float32))
+    other = round_to_bf16(rng.uniform(-1, 1, (3, H, W, 64)).astype(np.float32))
+    w = round_to_bf16((rng.standard_normal((3, 3, 64, 64)) / 24).astype(np.float32))
+    b = rng.uniform(-0.1, 0.1, 64).astype(np.float32)
+    xd, od = _dev(ctx, x, torch.bfloat16), _dev(ctx, other, torch.bfloat16)
+    conv = O.conv2d(x, w, b, dtype=np.float64)
+    if which == 1:      # x is skip 1, alone
+        ref = 0.2 * conv + x
+        got = ctx.conv2d(xd, w, b, alpha=0.2, skip1=xd, beta1=1.0)
+    else:               # RRDB tail: another tensor is skip 1, x is skip 2
+        ref = 0.04 * conv + other + 0.2 * x
+        got = ctx.conv2d(xd, w, b, alpha=0.04, skip1=od, beta1=1.0, skip2=xd, beta2=0.2)
+    assert rel_l2(got.float().cpu().numpy(), ref) <= 1e-2
+    # and against the same op with the skip passed as a separate copy (HBM path): equal up to one bf16 ulp of fp32 re-association
+    xc = xd.clone()
+    got2 = ctx.conv2d(xd, w, b, alpha=0.2, skip1=xc, beta1=1.0) if which == 1 else \
+        ctx.conv2d(xd, w, b, alpha=0.04, skip1=od, beta1=1.0, skip2=xc, beta2=0.2)
+    d = (got.float() - got2.float()).abs().max().item()
+    assert d <= 2 ** -6 * max(1.0, float(np.abs(ref).max())), d
+
+
 @pytest.mark.parametrize("r,cout", [(2, 256), (3, 72), (2, 12)])
 def test_conv2d_depth_to_space_dcr(ctx, r, cout):
     """TF depth_to_space is DCR: out[b,h*r+i,w*r+j,c] = in[b,h,w,(i*r+j)*C+c] (not torch pixel_shuffle)."""
