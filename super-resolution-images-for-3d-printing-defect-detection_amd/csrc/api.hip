@@ -84,7 +84,7 @@ struct Op {
     int act = SR_ACT_LINEAR; float alpha = 1.f, beta1 = 0.f, beta2 = 0.f; int clip = 0, d2s = 1;
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
 };
-struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; };   // vec: fp32 [B,C]
+struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h)
 struct ConvPart { std::string name; int cout; };
 struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; };
 
@@ -211,6 +211,10 @@ int build_esrgan(sr_model* m) {
     m->bufs[x0].Cbuf = b.E();
     const int trunk = b.buf(64);
     int cat[3] = {b.buf(CC), b.buf(CC), b.buf(CC)};
+    // The concat buffers are only ever touched by convs (written by initial_conv / the dense convs, read by the bf16 3x3
+    // kernel): keep them row-blocked so that a 32-channel chunk of a tile row is one contiguous run of whole 128-byte lines.
+    if (m->T == SR_DTYPE_BF16 && G % 32 == 0)
+        for (int i = 0; i < 3; ++i) m->bufs[cat[i]].blk = 1;
     Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
     b.conv("initial_conv", 3, C, 64, {x0, 0}, {trunk, 0});
     b.conv_again((int)m->convs.size() - 1, {x0, 0}, {cat[0], 0});   // same layer again, straight into the first concat buffer
@@ -536,16 +540,16 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 break;
             case OP_CONV: {
                 const ConvSpec& cs = m->convs[op.conv];
-                TensorView xin{m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff};
+                TensorView xin{m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, m->bufs[op.in.buf].blk};
                 ConvEpilogue ep;
                 ep.act = op.act; ep.alpha = op.alpha; ep.clip01 = op.clip; ep.d2s_r = op.d2s;
-                if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff}; ep.beta1 = op.beta1; }
-                if (op.skip2.buf >= 0) { ep.skip2 = {m->bufp[op.skip2.buf], m->bufs[op.skip2.buf].Cbuf, op.skip2.coff}; ep.beta2 = op.beta2; }
+                if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff, m->bufs[op.skip1.buf].blk}; ep.beta1 = op.beta1; }
+                if (op.skip2.buf >= 0) { ep.skip2 = {m->bufp[op.skip2.buf], m->bufs[op.skip2.buf].Cbuf, op.skip2.coff, m->bufs[op.skip2.buf].blk}; ep.beta2 = op.beta2; }
                 if (op.out.buf == -2) {
                     ep.out_f32 = io_dtype == SR_DTYPE_F32;
                     rc = conv_launch(ctx, cs.w, xin, B, h, w, y, m->out_C, 0, ep, st);
                 } else {
-                    rc = conv_launch(ctx, cs.w, xin, B, h, w, m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, ep, st);
+                    rc = conv_launch(ctx, cs.w, xin, B, h, w, TensorView{m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, m->bufs[op.out.buf].blk}, ep, st);
                 }
                 break;
             }

@@ -76,6 +76,7 @@ struct TensorView {           // NHWC view with a channel stride/offset (element
     const void* p = nullptr;
     int64_t cs = 0;           // channels per pixel in the underlying buffer
     int coff = 0;             // first channel of this view
+    int blk = 0;              // 1: the buffer is row-blocked, [B][H][cs/32][W][32] (conv_common.h); cs, coff multiples of 32
 };
 
 struct ConvEpilogue {
@@ -95,6 +96,7 @@ void conv_free_weights(sr_ctx* ctx, ConvWeights* w);
 // x view must expose >= w.CinP channels starting at coff (extra ones multiplied by zero weights).
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W,
                 void* y, int64_t y_cs, int y_coff, const ConvEpilogue& ep, hipStream_t st);
+int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W, TensorView y, const ConvEpilogue& ep, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // attention core: o = softmax(q k^T) v per image, tokens N=H*W.

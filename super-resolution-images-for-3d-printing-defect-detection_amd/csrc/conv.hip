@@ -425,6 +425,13 @@ void conv_free_weights(sr_ctx* ctx, ConvWeights* w) {
 
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W, void* y, int64_t y_cs, int y_coff,
                 const ConvEpilogue& ep, hipStream_t st) {
+    return conv_launch(ctx, w, x, B, H, W, TensorView{y, y_cs, y_coff}, ep, st);
+}
+
+int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W, TensorView yv, const ConvEpilogue& ep, hipStream_t st) {
+    void* y = const_cast<void*>(yv.p);
+    const int64_t y_cs = yv.cs;
+    const int y_coff = yv.coff;
     if (B <= 0 || H <= 0 || W <= 0) return ctx->fail(SR_ERR_INVALID, "conv: empty tensor");
     const int esz = dtype_size(w.dtype);
     if ((x.cs * esz) % 16 != 0 || (x.coff * esz) % 16 != 0 || ((uintptr_t)x.p % 16) != 0)
@@ -433,14 +440,25 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     if ((int64_t)H * W * x.cs >= (int64_t)1 << 31) return ctx->fail(SR_ERR_INVALID, "conv: image too large for 32-bit offsets");
     const int r = ep.d2s_r < 1 ? 1 : ep.d2s_r;
     if (w.Cout % (r * r) != 0) return ctx->fail(SR_ERR_INVALID, "conv: Cout not divisible by d2s block^2");
+    // effective strides of a view (conv_common.h): NHWC or row-blocked
+    auto strides = [&](const TensorView& v, int width, int64_t* cs, int* ps, int* rs) {
+        if (v.blk) { *cs = 32; *ps = width * 32; *rs = (int)(width * v.cs); }
+        else { *cs = v.cs; *ps = 32; *rs = (int)(width * v.cs); }
+    };
+    for (const TensorView* v : {(const TensorView*)&x, (const TensorView*)&yv, &ep.skip1, &ep.skip2})
+        if (v->p && v->blk && (v->cs % 32 != 0 || v->coff % 32 != 0)) return ctx->fail(SR_ERR_INVALID, "conv: a row-blocked view needs 32-channel granularity");
+    if (x.blk && !w.rows) return ctx->fail(SR_ERR_INVALID, "conv: only the bf16 3x3 kernel reads row-blocked inputs");
+    if (yv.blk && r > 1) return ctx->fail(SR_ERR_INVALID, "conv: depth_to_space writes NHWC only");
     ConvParams p;
-    p.in = static_cast<const char*>(x.p); p.in_cs = x.cs; p.in_coff = x.coff;
+    p.in = static_cast<const char*>(x.p); p.in_coff = x.coff; strides(x, W, &p.in_cs, &p.in_ps, &p.in_rs);
     p.w = static_cast<const char*>(w.w); p.bias = w.bias;
-    p.out = static_cast<char*>(y); p.out_cs = y_cs; p.out_coff = y_coff;
+    p.out = static_cast<char*>(y); p.out_coff = y_coff; strides(yv, W * r, &p.out_cs, &p.out_ps, &p.out_rs);
     p.out_f32 = (ep.out_f32 || w.dtype == SR_DTYPE_F32) ? 1 : 0;
-    p.s1 = static_cast<const char*>(ep.skip1.p); p.s1_cs = ep.skip1.cs; p.s1_coff = ep.skip1.coff; p.beta1 = ep.beta1;
-    p.s2 = static_cast<const char*>(ep.skip2.p); p.s2_cs = ep.skip2.cs; p.s2_coff = ep.skip2.coff; p.beta2 = ep.beta2;
-    if (!p.s1 && p.s2) { p.s1 = p.s2; p.s1_cs = p.s2_cs; p.s1_coff = p.s2_coff; p.beta1 = p.beta2; p.s2 = nullptr; }   // a lone skip is skip 1
+    p.s1 = static_cast<const char*>(ep.skip1.p); p.s1_coff = ep.skip1.coff; p.beta1 = ep.beta1; strides(ep.skip1, W, &p.s1_cs, &p.s1_ps, &p.s1_rs);
+    p.s2 = static_cast<const char*>(ep.skip2.p); p.s2_coff = ep.skip2.coff; p.beta2 = ep.beta2; strides(ep.skip2, W, &p.s2_cs, &p.s2_ps, &p.s2_rs);
+    if (!p.s1 && p.s2) {   // a lone skip is skip 1
+        p.s1 = p.s2; p.s1_cs = p.s2_cs; p.s1_coff = p.s2_coff; p.s1_ps = p.s2_ps; p.s1_rs = p.s2_rs; p.beta1 = p.beta2; p.s2 = nullptr;
+    }
     p.alpha = ep.alpha; p.act = ep.act; p.clip = ep.clip01; p.r = r; p.Cd = w.Cout / (r * r);
     p.B = B; p.H = H; p.W = W; p.Cout = w.Cout; p.nchunks = w.nchunks; p.tilesX = p.tilesY = 0;
     p.dbg = ctx->stamp_buf;
@@ -453,8 +471,8 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     // from the LDS image of those channels while they are staged, instead of reading it again in the epilogue (conv_rows.hip)
     p.skip_lds = 0; p.skip_scale = 0.f;
     if (w.rows && w.NT == 4 && w.Cout % 16 == 0 && w.Cin >= w.Cout && ep.act == SR_ACT_LINEAR && ep.alpha != 0.f && r == 1 && vec) {
-        if (p.s2 && p.s2 == p.in && p.s2_cs == p.in_cs && p.s2_coff == p.in_coff) { p.skip_lds = 2; p.skip_scale = p.beta2 / p.alpha; }
-        else if (p.s1 && p.s1 == p.in && p.s1_cs == p.in_cs && p.s1_coff == p.in_coff) { p.skip_lds = 1; p.skip_scale = p.beta1 / p.alpha; }
+        if (p.s2 && p.s2 == p.in && p.s2_cs == p.in_cs && p.s2_ps == p.in_ps && p.s2_coff == p.in_coff) { p.skip_lds = 2; p.skip_scale = p.beta2 / p.alpha; }
+        else if (p.s1 && p.s1 == p.in && p.s1_cs == p.in_cs && p.s1_ps == p.in_ps && p.s1_coff == p.in_coff) { p.skip_lds = 1; p.skip_scale = p.beta1 / p.alpha; }
     }
     const int nct = w.CoutP / 32 / w.NT;
     int rec = -1;

@@ -4,12 +4,17 @@
 
 namespace convk {
 
+// A tensor view is addressed as  base + (b*H + y)*rs + x*cs + choff(coff + c),  choff(c) = (c >> 5)*ps + (c & 31)  (elements):
+//   NHWC                : cs = channels of the buffer, ps = 32 (so choff(c) = c), rs = W*cs;
+//   row-blocked (blk)   : [B][H][C/32][W][32] -- cs = 32, ps = W*32, rs = W*C.  A 32-channel block of an image row is contiguous,
+//                         so the 3x3 kernel's per-chunk reads and its 32-cout writes move whole 128-byte lines
+//                         (only conv_rows reads such views, any conv epilogue can write them).
 struct ConvParams {
-    const char* in; int64_t in_cs; int in_coff;
+    const char* in; int64_t in_cs; int in_coff; int in_ps; int in_rs;
     const char* w; const float* bias;
-    char* out; int64_t out_cs; int out_coff; int out_f32;
-    const char* s1; int64_t s1_cs; int s1_coff; float beta1;
-    const char* s2; int64_t s2_cs; int s2_coff; float beta2;
+    char* out; int64_t out_cs; int out_coff; int out_ps; int out_rs; int out_f32;
+    const char* s1; int64_t s1_cs; int s1_coff; int s1_ps; int s1_rs; float beta1;
+    const char* s2; int64_t s2_cs; int s2_coff; int s2_ps; int s2_rs; float beta2;
     float alpha; int act; int clip; int r; int Cd;
     int B, H, W, Cout;
     int nchunks;        // wide: Cin chunks; thin: number of k-groups (taps pairs)
@@ -19,6 +24,8 @@ struct ConvParams {
     float skip_scale;   // its beta / alpha
     unsigned long long* dbg;   // diagnostic builds only: 16 s_memtime stamps per workgroup (sr_debug_set_stamp_buffer)
 };
+
+__device__ __forceinline__ int choff(int c, int ps) { return (c >> 5) * ps + (c & 31); }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
@@ -55,12 +62,13 @@ template <> __device__ __forceinline__ void store4<bf16_t>(char* base, int64_t e
 
 
 // Fused epilogue for one output pixel (b, oy, ox) and the 4 consecutive output channels starting at c0:
-// bias, activation, alpha, two scaled skips, clip[0,1], then an NHWC store or a depth_to_space (TF "DCR") store.
+// bias, activation, alpha, two scaled skips, clip[0,1], then a store into the output view or a depth_to_space (TF "DCR")
+// store (NHWC output only: the host rejects a row-blocked output with d2s).
 template <typename T>
 __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, int ox, int c0, const float a[4]) {
     if (c0 >= p.Cout) return;
     const bool vec = p.vec != 0;
-    const int64_t pix = ((int64_t)b * p.H + oy) * p.W + ox;
+    const int64_t row = (int64_t)b * p.H + oy;
     const int nv = min(4, p.Cout - c0);
     const bool v4 = vec && nv == 4;
     float v[4];
@@ -68,13 +76,13 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, in
     for (int e = 0; e < 4; ++e) v[e] = act_apply(a[e] + p.bias[c0 + e], p.act) * p.alpha;
     if (p.s1) {
         float s[4];
-        load4<T>(p.s1, pix * p.s1_cs + p.s1_coff + c0, v4, nv, s);
+        load4<T>(p.s1, row * p.s1_rs + ox * p.s1_cs + choff(p.s1_coff + c0, p.s1_ps), v4, nv, s);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += p.beta1 * s[e];
     }
     if (p.s2) {
         float s[4];
-        load4<T>(p.s2, pix * p.s2_cs + p.s2_coff + c0, v4, nv, s);
+        load4<T>(p.s2, row * p.s2_rs + ox * p.s2_cs + choff(p.s2_coff + c0, p.s2_ps), v4, nv, s);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += p.beta2 * s[e];
     }
@@ -83,7 +91,7 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, in
         for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
     }
     if (p.r <= 1) {
-        store4<T>(p.out, pix * p.out_cs + p.out_coff + c0, v4, nv, v, p.out_f32 != 0);
+        store4<T>(p.out, row * p.out_rs + ox * p.out_cs + choff(p.out_coff + c0, p.out_ps), v4, nv, v, p.out_f32 != 0);
     } else if (v4) {   // Cd % 4 == 0 guaranteed by the host when vec
         const int sub = c0 / p.Cd, c = c0 - sub * p.Cd;
         const int i = sub / p.r, j = sub - i * p.r;

@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
     const int ty = t % p.tilesY;
     const int b = t / p.tilesY;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int H = p.H, W = p.W, in_cs = (int)p.in_cs;
-    const bf16_t* inb = reinterpret_cast<const bf16_t*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;   // wave-uniform
+    const int H = p.H, W = p.W, in_cs = (int)p.in_cs, in_rs = p.in_rs, in_ps = p.in_ps;
+    const bf16_t* inb = reinterpret_cast<const bf16_t*>(p.in) + (int64_t)b * H * in_rs + choff(p.in_coff, in_ps);   // wave-uniform
 
     int soff[NINT], doff[NINT];   // 32-bit element offset inside the image (-1: zero fill) / LDS byte offset (-1: none)
 #pragma unroll
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
         const bool live = u < NIN;
         const bool inside = live && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         doff[i] = live ? pix * 64 + ((sl * 16) ^ ((pix & 4) << 3)) : -1;
-        soff[i] = inside ? (gy * W + gx) * in_cs + sl * 8 : -1;
+        soff[i] = inside ? gy * in_rs + gx * in_cs + sl * 8 : -1;
     }
     // Skip from LDS (p.skip_lds = 1 or 2): that skip tensor IS input channels [0, Cout) of this conv (a dense block adding its
     // own input back; linear activation, host-checked).  Cout block g then needs x channels 16g..16g+15 at the centre pixel,
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
 #pragma unroll
         for (int i = 0; i < NINT; ++i) {
             const int so = soff[i];
-            const bf16_t* ptr = inb + (so >= 0 ? so + chunk * 32 : 0);   // always a valid address; zero-select happens after landing
+            const bf16_t* ptr = inb + (so >= 0 ? so + chunk * in_ps : 0);   // always a valid address; zero-select happens after landing
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[i]) : "v"(ptr) : "memory");
         }
     };
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
     for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
     if constexpr (SKIP_LDS_OK) if (skip_lds) {
         ConvParams pe = p;                                                  // the epilogue sees only the other skip, as skip 1
-        if (p.skip_lds == 1) { pe.s1 = p.s2; pe.s1_cs = p.s2_cs; pe.s1_coff = p.s2_coff; pe.beta1 = p.beta2; }
+        if (p.skip_lds == 1) { pe.s1 = p.s2; pe.s1_cs = p.s2_cs; pe.s1_coff = p.s2_coff; pe.s1_ps = p.s2_ps; pe.s1_rs = p.s2_rs; pe.beta1 = p.beta2; }
         pe.s2 = nullptr;
         rows_epilogue<NB16, R>(pe, acc, biasv, b, y0, x0, ct, wave, px, q);
         STAMP_AT(15);

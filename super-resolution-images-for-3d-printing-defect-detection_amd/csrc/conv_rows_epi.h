@@ -28,7 +28,6 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     const float slope = p.act == SR_ACT_RELU ? 0.f : (p.act == SR_ACT_LRELU ? 0.2f : 1.f);
     const float alpha = p.alpha, beta1 = p.beta1, beta2 = p.beta2;
     const bool clip = p.clip != 0, of32 = p.out_f32 != 0;
-    const int64_t img_pix = (int64_t)b * H * W;           // wave-uniform
 
     // ---- skip values are loaded a row group at a time, ahead of that group's stores: the whole tile at once, or two
     //      halves where both skips are present and the register budget is the 3-workgroups-per-CU one (NB16 <= 2)
@@ -36,7 +35,6 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     int cc[NB16];
 #pragma unroll
     for (int n = 0; n < NB16; ++n) cc[n] = min((ct * NB16 + n) * 16 + 4 * q, p.Cout - 4);
-    const int l1 = HAS1 ? oxc * (int)p.s1_cs + p.s1_coff : 0, l2 = HAS2 ? oxc * (int)p.s2_cs + p.s2_coff : 0;
 
     // ---- store addressing: NS stores per row; store s of row r goes to element rb[s] + r*rstep (uniform) + loff[s] (lane)
     constexpr int NS = PAIR ? NB16 / 2 : NB16;
@@ -44,7 +42,7 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     int loff[NS];
     int64_t rb[NS];
     bool live[NS];
-    const int64_t rstep = rr_ <= 1 ? (int64_t)W * p.out_cs : (int64_t)rr_ * W * rr_ * p.out_cs;
+    const int64_t rstep = rr_ <= 1 ? (int64_t)p.out_rs : (int64_t)rr_ * p.out_rs;   // (with d2s the host sets out_rs for the r-times wider output row)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         // PAIR: lanes q and q^1 trade halves (v_permlane16_swap): an even-q lane stores 8 consecutive couts of block 2s,
@@ -53,12 +51,12 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
         const int lane_c = PAIR ? (q & 1) * 16 + 4 * (q & ~1) : 4 * q;
         live[s] = col_ok && (PAIR || blk + lane_c < p.Cout);
         if (rr_ <= 1) {
-            rb[s] = (img_pix + (int64_t)oyw * W) * p.out_cs;
-            loff[s] = ox * (int)p.out_cs + p.out_coff + blk + lane_c;
+            rb[s] = ((int64_t)b * H + oyw) * p.out_rs;
+            loff[s] = ox * (int)p.out_cs + choff(p.out_coff + blk + lane_c, p.out_ps);
         } else {   // TF depth_to_space "DCR": cout = (i*r + j)*Cd + c.  Cd % 16 == 0 (% 32 for PAIR): (i, j) uniform per store
             const int sub = blk / Cd, cb = blk - sub * Cd;
             const int i = sub / rr_, j = sub - i * rr_;
-            rb[s] = (img_pix * rr_ * rr_ + ((int64_t)oyw * rr_ + i) * ((int64_t)W * rr_)) * p.out_cs;
+            rb[s] = (((int64_t)b * H + oyw) * rr_ + i) * p.out_rs;
             loff[s] = (ox * rr_ + j) * (int)p.out_cs + p.out_coff + cb + lane_c;
         }
     }
@@ -70,11 +68,11 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     if (HAS1 || HAS2) {
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
-            const int64_t rowpix = img_pix + (int64_t)(oyw + (r0 + g < rows ? r0 + g : 0)) * W;   // dead rows re-read row 0: valid memory
+            const int64_t row = (int64_t)b * H + (oyw + (r0 + g < rows ? r0 + g : 0));           // dead rows re-read row 0: valid memory
 #pragma unroll
             for (int n = 0; n < NB16; ++n) {
-                if (HAS1) k1[g][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s1) + rowpix * p.s1_cs + (l1 + cc[n]));
-                if (HAS2) k2[g][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s2) + rowpix * p.s2_cs + (l2 + cc[n]));
+                if (HAS1) k1[g][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s1) + row * p.s1_rs + (oxc * (int)p.s1_cs + choff(p.s1_coff + cc[n], p.s1_ps)));
+                if (HAS2) k2[g][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s2) + row * p.s2_rs + (oxc * (int)p.s2_cs + choff(p.s2_coff + cc[n], p.s2_ps)));
             }
         }
     }
