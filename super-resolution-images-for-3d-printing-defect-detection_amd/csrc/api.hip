@@ -85,7 +85,7 @@ struct Op {
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
 };
 struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h)
-struct ConvPart { std::string name; int cout; };
+struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
 struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; };
 
 }  // namespace
@@ -143,7 +143,10 @@ struct Builder {
     }
     // SelfAttention(64) on `x` (64 ch) -> `y` (64 ch); qkv: 64-ch scratch, ao: 32-ch scratch (same resolution)
     void self_attention(const std::string& name, int x, int y, int qkv, int ao) {
-        Op p; p.kind = OP_CONV; p.conv = conv_spec({{name + "_f", 8}, {name + "_g", 8}, {name + "_h", 32}}, 1, 64);
+        // bf16: the key projection f is packed pre-multiplied by log2(e) -- the attention kernel works in the exp2 domain and has the
+        // matrix core subtract the running max (attention.hip), so nothing is left to scale per score
+        const float kscale = m->T == SR_DTYPE_BF16 ? 1.4426950408889634f : 1.f;
+        Op p; p.kind = OP_CONV; p.conv = conv_spec({{name + "_f", 8, kscale}, {name + "_g", 8}, {name + "_h", 32}}, 1, 64);
         p.in = {x, 0}; p.out = {qkv, 0}; m->ops.push_back(p);
         Op a; a.kind = OP_ATTN; a.in = {qkv, 0}; a.out = {ao, 0}; m->ops.push_back(a);
         Op& v = conv(name + "_v", 1, 32, 64, {ao, 0}, {y, 0});
@@ -483,8 +486,8 @@ int sr_model_finalize(sr_model* m) {
             for (int t = 0; t < taps; ++t)
                 for (int ci = 0; ci < c.Cin; ++ci)
                     for (int co = 0; co < part.cout; ++co)
-                        k[((size_t)t * c.Cin + ci) * c.Cout + co0 + co] = pk.host[((size_t)t * c.Cin + ci) * part.cout + co];
-            for (int co = 0; co < part.cout; ++co) bias[co0 + co] = pb.host[co];
+                        k[((size_t)t * c.Cin + ci) * c.Cout + co0 + co] = part.scale * pk.host[((size_t)t * c.Cin + ci) * part.cout + co];
+            for (int co = 0; co < part.cout; ++co) bias[co0 + co] = part.scale * pb.host[co];
             co0 += part.cout;
         }
         int rc = conv_pack_weights(ctx, k.data(), bias.data(), c.KS, c.Cin, c.Cout, m->T, &c.w);
@@ -624,12 +627,13 @@ int sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W
     if (dtype != SR_DTYPE_F32 && dtype != SR_DTYPE_BF16) return ctx->fail(SR_ERR_INVALID, "dtype must be f32 or bf16");
     if (B <= 0 || H <= 0 || W <= 0) return ctx->fail(SR_ERR_INVALID, "bad tensor shape");
     // f | g | h side by side: one 1x1 conv 64 -> 48
+    const float kscale = dtype == SR_DTYPE_BF16 ? 1.4426950408889634f : 1.f;   // see Builder::self_attention
     std::vector<float> wp((size_t)64 * 48), bp(48);
     for (int ci = 0; ci < 64; ++ci) {
-        for (int co = 0; co < 8; ++co) { wp[(size_t)ci * 48 + co] = wf[ci * 8 + co]; wp[(size_t)ci * 48 + 8 + co] = wg[ci * 8 + co]; }
+        for (int co = 0; co < 8; ++co) { wp[(size_t)ci * 48 + co] = kscale * wf[ci * 8 + co]; wp[(size_t)ci * 48 + 8 + co] = wg[ci * 8 + co]; }
         for (int co = 0; co < 32; ++co) wp[(size_t)ci * 48 + 16 + co] = wh[ci * 32 + co];
     }
-    for (int co = 0; co < 8; ++co) { bp[co] = bf ? bf[co] : 0.f; bp[8 + co] = bg ? bg[co] : 0.f; }
+    for (int co = 0; co < 8; ++co) { bp[co] = bf ? kscale * bf[co] : 0.f; bp[8 + co] = bg ? bg[co] : 0.f; }
     for (int co = 0; co < 32; ++co) bp[16 + co] = bh ? bh[co] : 0.f;
     ConvWeights cp, cv;
     int rc = conv_pack_weights(ctx, wp.data(), bp.data(), 1, 64, 48, dtype, &cp);

@@ -196,8 +196,6 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
     const int b = blockIdx.x / nqt, qt = blockIdx.x - b * nqt;
     const bf16_t* base = reinterpret_cast<const bf16_t*>(p.qkv) + (int64_t)b * N * p.cs;
     const int cs = (int)p.cs;
-    const float LOG2E = 1.4426950408889634f;
-
     int qi[QB];
     bf16x8 qb[QB];
 #pragma unroll
@@ -205,21 +203,27 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
         qi[j] = qt * QW + wave * (32 * QB) + j * 32 + r;
         const int qc = qi[j] < N ? qi[j] : N - 1;
         bf16x8 z = {};
-        qb[j] = z;
+        qb[j] = z;                                     // h == 1 lanes: K-slots 8..15; slots 8, 9 will carry the running max
         if (h == 0) qb[j] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qc * cs + p.qoff);
     }
     f32x16 oacc[QB];
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
-        m_run[j] = -INFINITY; l_run[j] = 0.f;
+        m_run[j] = 0.f; l_run[j] = 0.f;              // the first key tile sets m_run unconditionally (first = true)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
     }
 
     const int kp = tid >> 2, oct = tid & 3;    // V staging: key pair, 8-channel octet
+    // Key fragment (A operand): lanes h == 0 hold the 8 key dims, lanes h == 1 hold K-slots 8..15 = {-1, -1, -1, 0, ...}.  With the
+    // query fragment's slots 8..10 = the running max split into three bf16 pieces (exact to fp32), the score MFMA returns  k.q - m  directly: the running max is subtracted
+    // inside the matrix core and the softmax loop has no multiply/subtract per score left.  (k is pre-scaled by log2(e) in the
+    // projection conv, api.hip, so the scores arrive in the exp2 domain.)
+    bf16x8 kneg = {};
+    kneg[0] = (bf16_t)-1.f; kneg[1] = (bf16_t)-1.f; kneg[2] = (bf16_t)-1.f;
     auto load_k = [&](int kb) {
-        bf16x8 kf = {};
+        bf16x8 kf = kneg;
         const int key = kb + r;
         if (h == 0) kf = *reinterpret_cast<const bf16x8*>(base + (int64_t)(key < N ? key : N - 1) * cs + p.koff);
         return kf;
@@ -235,9 +239,9 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
         const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
     };
-    auto tile = [&](const bf16x8 kf, const int sub, const int kb, auto ragged_tag) {
+    auto tile = [&](const bf16x8 kf, const int sub, const int kb, auto ragged_tag, const bool first) {
         constexpr bool RAGGED = sizeof(ragged_tag) > 1;
-        // phase A (both query blocks, no control flow in between): scores and their column maxima
+        // phase A (both query blocks, no control flow in between): scores relative to the running max, and their column maxima
         f32x16 s[QB];
         float mx[QB];
 #pragma unroll
@@ -252,30 +256,38 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
 #pragma unroll
             for (int i = 3; i + 1 < 16; i += 2) m = fmaxf(fmaxf(m, s[j][i]), s[j][i + 1]);
             m = fmaxf(m, s[j][15]);
-            mx[j] = hmax(m) * LOG2E;
+            mx[j] = hmax(m);                            // > 0: a score above the running max
         }
-        // phase B: one wave-uniform vote for both blocks; rescale only when a running max grew
-        bool grew = false;
+        // phase B: one wave-uniform vote for both blocks; only when a running max grew (or on the first tile) are the
+        // accumulators rescaled, the scores shifted and the max pieces in the query fragment refreshed
+        bool grew = first;
 #pragma unroll
-        for (int j = 0; j < QB; ++j) grew = grew || mx[j] > m_run[j];
+        for (int j = 0; j < QB; ++j) grew = grew || mx[j] > 0.f;
         if (__any(grew)) {
 #pragma unroll
             for (int j = 0; j < QB; ++j) {
-                const float m_new = fmaxf(m_run[j], mx[j]);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);   // exp2(-inf) = 0 first; exp2(0) = 1 exactly
+                const float delta = first ? mx[j] : fmaxf(mx[j], 0.f);
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // first tile: l_run = oacc = 0, and exp2(-delta) may be +inf
                 l_run[j] *= alpha;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) oacc[j][e] *= alpha;
-                m_run[j] = m_new;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[j][i] -= delta;
+                m_run[j] += delta;
+                if (h == 1) {                                             // m = m1 + m2 + m3: three bf16 pieces carry all 24 bits
+                    const bf16_t m1 = (bf16_t)m_run[j];
+                    const float r1 = m_run[j] - (float)m1;
+                    const bf16_t m2 = (bf16_t)r1;
+                    qb[j][0] = m1; qb[j][1] = m2; qb[j][2] = (bf16_t)(r1 - (float)m2);
+                }
             }
         }
         // phase C (both blocks interleavable): probabilities, row sums, O^T += V^T . P^T
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
-            const float nm = -m_run[j];
             float psum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[j][i] = __builtin_amdgcn_exp2f(fmaf(s[j][i], LOG2E, nm)); psum += s[j][i]; }
+            for (int i = 0; i < 16; ++i) { s[j][i] = __builtin_amdgcn_exp2f(s[j][i]); psum += s[j][i]; }
             l_run[j] += psum;
         }
 #pragma unroll
@@ -314,8 +326,8 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
             if (kb >= N) break;
             const bf16x8 kf = knext;
             knext = load_k(kb + 32);                       // next tile's keys fly under this tile's softmax
-            if (kb + 32 <= N) tile(kf, sub, kb, false_c);  // full tile: no masking code at all
-            else tile(kf, sub, kb, true_c);                // ragged last tile: keys >= N get -inf
+            if (kb + 32 <= N) tile(kf, sub, kb, false_c, kb == 0);  // full tile: no masking code at all
+            else tile(kf, sub, kb, true_c, kb == 0);                // ragged last tile: keys >= N get -inf
         }
     }
 #pragma unroll

@@ -153,6 +153,30 @@ def test_self_attention_forced_max_jump(ctx):
     assert rel_l2(got, ref) <= 2e-5
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("sign", [-1.0, 1.0])
+def test_self_attention_large_uniform_scores(ctx, sign, dtype):
+    """Scores far from zero: q.k = -/+400 for every pair plus small noise.  With the negative sign the first key tile's row maximum
+    is far below zero (the running max starts there, exp2 of its negation overflows); with the positive sign the exponent range is
+    used from the other end.  The softmax is shift-invariant, so the result must still match the fp64 oracle."""
+    rng = np.random.default_rng(23)
+    H, W = 12, 20                                   # N = 240: seven full key tiles + a ragged one
+    x = (0.05 * rng.standard_normal((2, H, W, 64))).astype(np.float32)
+    x[..., 0] = 20.0
+    ws = _sa_weights(rng)
+    ws[0][0, 0, 0, :] = 0.0; ws[0][0, 0, 0, 0] = 1.0          # f (keys):    dim 0 <- +channel 0
+    ws[2][0, 0, 0, :] = 0.0; ws[2][0, 0, 0, 0] = sign * 1.0   # g (queries): dim 0 <- +/- channel 0
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    if dtype == "bf16":
+        x = round_to_bf16(x)
+        ws = [round_to_bf16(a) if a.ndim == 4 else a for a in ws]
+    ref = O.self_attention(x, *ws, dtype=np.float64)
+    got = ctx.self_attention(_dev(ctx, x, td), *ws).float().cpu().numpy()
+    assert np.isfinite(got).all()
+    # bf16: k and q are rounded to bf16 after the projection, so scores of magnitude 400 carry errors of order 1 -- compare loosely
+    assert rel_l2(got, ref) <= (2e-5 if dtype == "f32" else 1.5e-1), rel_l2(got, ref)
+
+
 # ------------------------------------------------------------------------------------------------ image ops
 @pytest.mark.parametrize("shape,out", [((1, 64, 64, 3), (256, 256)), ((2, 23, 31, 3), (46, 62)), ((1, 239, 239, 3), (478, 478)),
                                        ((1, 10, 10, 1), (37, 23))])

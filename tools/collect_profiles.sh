@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 TAG=${1:-r01}
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --steps 2 --warmup 1 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err" || { echo "bench profile failed"; tail -5 "$OUT/bench.err"; exit 1; }
 tail -1 "$OUT/${TAG}_bench.json" > "$OUT/${TAG}_bench.line" && mv "$OUT/${TAG}_bench.line" "$OUT/${TAG}_bench.json"
-cp "$(ls $OUT/bench/*/*kernel_stats.csv | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
+find "$OUT/bench" -type f | head -20; cp "$(find "$OUT/bench" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
 echo "bench + kernel stats done"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/probe_trunk.py 1764 2 > "$OUT/pmc_fetch.log" 2>&1 || { echo "FETCH_SIZE pass failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 echo "FETCH_SIZE pass done"

@@ -12,12 +12,12 @@ from sr355 import Context, Model
 from sr355.weights import init_weights
 
 ctx = Context.get(0)
-B = 441
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 441
 m = Model("esrgan_g", compute_dtype="bf16", scale_factor=4, num_blocks=1, growth_channels=32, use_attention=False, ctx=ctx)
 m.set_weights(init_weights(m.layer_shapes(), seed=3000))
 x = ctx.to_device(np.random.default_rng(0).uniform(-1, 1, (B, 48, 48, 3)).astype(np.float32))
 m.forward(x); torch.cuda.synchronize()
-nwg_max = 441 * 9 * 16 * 4 * 4
+nwg_max = B * 9 * 16 * 4 * 4
 buf = torch.zeros(nwg_max * 16, dtype=torch.int64, device="cuda")
 ctx.lib.sr_debug_set_stamp_buffer(ctx.h, buf.data_ptr())
 m.forward(x); torch.cuda.synchronize()
