@@ -76,7 +76,7 @@ struct Param {
     int64_t count() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
 };
 struct Ref { int buf = -1; int coff = 0; };        // buf: >=0 internal, -1 none, -2 caller's y
-enum OpKind { OP_CONVERT, OP_CONV, OP_ATTN, OP_POOL, OP_GAP, OP_DENSE };
+enum OpKind { OP_CONVERT, OP_CONV, OP_ATTN, OP_POOL, OP_GAP, OP_DENSE, OP_TOBLK };
 struct Op {
     OpKind kind = OP_CONV;
     Ref in, out, skip1, skip2;
@@ -220,7 +220,11 @@ int build_esrgan(sr_model* m) {
         for (int i = 0; i < 3; ++i) m->bufs[cat[i]].blk = 1;
     Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
     b.conv("initial_conv", 3, C, 64, {x0, 0}, {trunk, 0});
-    b.conv_again((int)m->convs.size() - 1, {x0, 0}, {cat[0], 0});   // same layer again, straight into the first concat buffer
+    if (m->bufs[cat[0]].blk) {        // the trunk input also goes into the first concat buffer: a layout-changing copy of 64 channels
+        Op t; t.kind = OP_TOBLK; t.in = {trunk, 0}; t.out = {cat[0], 0}; m->ops.push_back(t);
+    } else {
+        b.conv_again((int)m->convs.size() - 1, {x0, 0}, {cat[0], 0});   // same layer again, straight into the first concat buffer
+    }
     int X = 0, Y = 1, Z = 2;                                          // cat[X] holds the RRDB input in channels [0,64)
     for (int r = 0; r < c.num_blocks; ++r) {
         const int src[3] = {X, Y, Z}, dst[3] = {Y, Z, Y};
@@ -559,6 +563,10 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
             case OP_ATTN:
                 rc = attention_launch(ctx, T, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, /*q=g*/ 8, /*k=f*/ 0, /*v=h*/ 16, B, h * w,
                                       m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, 0, st);
+                break;
+            case OP_TOBLK:
+                rc = nhwc_to_blocked_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.out.buf],
+                                            m->bufs[op.out.buf].Cbuf, op.out.coff, st);
                 break;
             case OP_POOL:
                 rc = maxpool2_launch(ctx, T, m->bufp[op.in.buf], B, h, w, m->bufs[op.in.buf].C, m->bufs[op.in.buf].Cbuf, m->bufp[op.out.buf],

@@ -110,6 +110,8 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
 // small ops (imgops.hip)
 // ---------------------------------------------------------------------------------------------
 // [B,H,W,C] of in_dtype -> [B,H,W,Cp] of out_dtype, channels >= C zero-filled, v*mul+add on real ones.
+int nhwc_to_blocked_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C,
+                           int dst_coff, hipStream_t st);
 int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype,
                        int Cp, float mul, float add, hipStream_t st);
 int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y,

@@ -447,7 +447,8 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     };
     for (const TensorView* v : {(const TensorView*)&x, (const TensorView*)&yv, &ep.skip1, &ep.skip2})
         if (v->p && v->blk && (v->cs % 32 != 0 || v->coff % 32 != 0)) return ctx->fail(SR_ERR_INVALID, "conv: a row-blocked view needs 32-channel granularity");
-    if (x.blk && !w.rows) return ctx->fail(SR_ERR_INVALID, "conv: only the bf16 3x3 kernel reads row-blocked inputs");
+    const bool any_blk = x.blk || yv.blk || (ep.skip1.p && ep.skip1.blk) || (ep.skip2.p && ep.skip2.blk);
+    if (any_blk && !w.rows) return ctx->fail(SR_ERR_INVALID, "conv: only the bf16 3x3 kernel handles row-blocked views");
     if (yv.blk && r > 1) return ctx->fail(SR_ERR_INVALID, "conv: depth_to_space writes NHWC only");
     ConvParams p;
     p.in = static_cast<const char*>(x.p); p.in_coff = x.coff; strides(x, W, &p.in_cs, &p.in_ps, &p.in_rs);
@@ -467,6 +468,8 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);
     if (p.s2) vec = vec && (p.s2_cs % 4 == 0) && (p.s2_coff % 4 == 0) && ((uintptr_t)p.s2 % (4 * esz) == 0);
     p.vec = vec ? 1 : 0;
+    if (any_blk && !(vec && w.Cout % 4 == 0 && ep.act != SR_ACT_TANH))   // conv_rows' generic per-element epilogue is NHWC-only
+        return ctx->fail(SR_ERR_INVALID, "conv: row-blocked views need the vector epilogue (aligned views, Cout % 4 == 0, no tanh)");
     // a dense block adds its own input back: when a skip is exactly input channels [0, Cout) of this conv, conv_rows folds it in
     // from the LDS image of those channels while they are staged, instead of reading it again in the epilogue (conv_rows.hip)
     p.skip_lds = 0; p.skip_scale = 0.f;

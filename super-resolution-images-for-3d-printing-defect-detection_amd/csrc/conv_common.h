@@ -8,7 +8,7 @@ namespace convk {
 //   NHWC                : cs = channels of the buffer, ps = 32 (so choff(c) = c), rs = W*cs;
 //   row-blocked (blk)   : [B][H][C/32][W][32] -- cs = 32, ps = W*32, rs = W*C.  A 32-channel block of an image row is contiguous,
 //                         so the 3x3 kernel's per-chunk reads and its 32-cout writes move whole 128-byte lines
-//                         (only conv_rows reads such views, any conv epilogue can write them).
+//                         (only conv_rows, with its fast epilogue, touches such views: conv_launch checks).
 struct ConvParams {
     const char* in; int64_t in_cs; int in_coff; int in_ps; int in_rs;
     const char* w; const float* bias;
@@ -26,7 +26,6 @@ struct ConvParams {
 };
 
 __device__ __forceinline__ int choff(int c, int ps) { return (c >> 5) * ps + (c & 31); }
-
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case SR_ACT_RELU: return fmaxf(v, 0.f);
@@ -62,13 +61,13 @@ template <> __device__ __forceinline__ void store4<bf16_t>(char* base, int64_t e
 
 
 // Fused epilogue for one output pixel (b, oy, ox) and the 4 consecutive output channels starting at c0:
-// bias, activation, alpha, two scaled skips, clip[0,1], then a store into the output view or a depth_to_space (TF "DCR")
-// store (NHWC output only: the host rejects a row-blocked output with d2s).
+// bias, activation, alpha, two scaled skips, clip[0,1], then an NHWC store or a depth_to_space (TF "DCR") store.  NHWC views
+// only: the host lets row-blocked views reach nothing but conv_rows' fast epilogue (conv_launch).
 template <typename T>
 __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, int ox, int c0, const float a[4]) {
     if (c0 >= p.Cout) return;
     const bool vec = p.vec != 0;
-    const int64_t row = (int64_t)b * p.H + oy;
+    const int64_t pix = ((int64_t)b * p.H + oy) * p.W + ox;
     const int nv = min(4, p.Cout - c0);
     const bool v4 = vec && nv == 4;
     float v[4];
@@ -76,13 +75,13 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, in
     for (int e = 0; e < 4; ++e) v[e] = act_apply(a[e] + p.bias[c0 + e], p.act) * p.alpha;
     if (p.s1) {
         float s[4];
-        load4<T>(p.s1, row * p.s1_rs + ox * p.s1_cs + choff(p.s1_coff + c0, p.s1_ps), v4, nv, s);
+        load4<T>(p.s1, pix * p.s1_cs + p.s1_coff + c0, v4, nv, s);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += p.beta1 * s[e];
     }
     if (p.s2) {
         float s[4];
-        load4<T>(p.s2, row * p.s2_rs + ox * p.s2_cs + choff(p.s2_coff + c0, p.s2_ps), v4, nv, s);
+        load4<T>(p.s2, pix * p.s2_cs + p.s2_coff + c0, v4, nv, s);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += p.beta2 * s[e];
     }
@@ -91,7 +90,7 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, in
         for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
     }
     if (p.r <= 1) {
-        store4<T>(p.out, row * p.out_rs + ox * p.out_cs + choff(p.out_coff + c0, p.out_ps), v4, nv, v, p.out_f32 != 0);
+        store4<T>(p.out, pix * p.out_cs + p.out_coff + c0, v4, nv, v, p.out_f32 != 0);
     } else if (v4) {   // Cd % 4 == 0 guaranteed by the host when vec
         const int sub = c0 / p.Cd, c = c0 - sub * p.Cd;
         const int i = sub / p.r, j = sub - i * p.r;

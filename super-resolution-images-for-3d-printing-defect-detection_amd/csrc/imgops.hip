@@ -328,6 +328,33 @@ inline unsigned grid_for(int64_t n, int block = 256) {
 }  // namespace
 
 // ================================================================================================
+// NHWC channels [src_coff, src_coff + C) -> the same channels of a row-blocked buffer [B][H][dst_C/32][W][32] at dst_coff (bf16;
+// C, offsets multiples of 32).  One 16-byte unit per thread, destination-linear within a 32-channel row segment.
+__global__ void nhwc_to_blocked_kernel(const bf16_t* src, int64_t src_cs, int src_coff, int64_t rows, int W, int C, bf16_t* dst, int64_t dst_C,
+                                       int dst_coff) {
+    const int64_t n = rows * (C / 32) * W * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(i & 3);
+        int64_t t = i >> 2;
+        const int x = (int)(t % W); t /= W;
+        const int cb = (int)(t % (C / 32));
+        const int64_t row = t / (C / 32);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (row * W + x) * src_cs + src_coff + cb * 32 + sl * 8);
+        *reinterpret_cast<bf16x8*>(dst + row * W * dst_C + (int64_t)(dst_coff / 32 + cb) * W * 32 + x * 32 + sl * 8) = v;
+    }
+}
+
+int nhwc_to_blocked_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C,
+                           int dst_coff, hipStream_t st) {
+    if (C % 32 || src_coff % 8 || dst_coff % 32 || dst_C % 32 || src_cs % 8) return ctx->fail(SR_ERR_INVALID, "nhwc_to_blocked: 32-channel granularity");
+    const int64_t n = (int64_t)B * H * (C / 32) * W * 4;
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(nhwc_to_blocked_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const bf16_t*>(src), src_cs, src_coff,
+                       (int64_t)B * H, W, C, static_cast<bf16_t*>(dst), dst_C, dst_coff);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
 int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype, int Cp, float mul,
                        float add, hipStream_t st) {
     if (npix <= 0) return SR_OK;
