@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 TILES_PER_GPU, LR, SCALE, NB, G, PATCH, STRIDE = 16, 512, 4, 23, 32, 48, 24
+PEAK_HBM_GBPS = 8000.0        # HBM3E, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
@@ -184,10 +185,21 @@ def main():
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
             if os.path.isfile(tp):
                 traffic = json.load(open(tp)).get(dom["kernel"])
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": dom["launches"],
-                    "flop_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
-                    "instrumented_ms_per_step": elapsed_prof / args.steps * 1e3}
+            # Which roof bounds the kernel: arithmetic intensity of its ALGORITHMIC work against the ridge of the two peaks
+            # (MI355X_MICROARCH.md: bf16 MFMA ~2.5 PFLOP/s dense, HBM3E ~8 TB/s -> 312 FLOP/B).  The dense-block convs with 32
+            # output channels sit at 192..247 FLOP/B: below the ridge, so the HBM roof is the one that bounds them.
+            ai = dom["flops"] / dom["bytes"]
+            tflops = ach
+            gbps = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+            common = {"kernel": dom["kernel"], "traffic": traffic, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                      "flop_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+                      "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBPS,
+                      "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_BF16_TFLOPS, "hbm_gbps": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS,
+                      "instrumented_ms_per_step": elapsed_prof / args.steps * 1e3}
+            if ai < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBPS:
+                roof = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common}
+            else:
+                roof = {"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS, **common}
         line = {
             "metric": "4x-SR MPix/s on 512x512 LR batch", "value": mpix * args.steps / elapsed, "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
