@@ -183,11 +183,12 @@ __global__ void __launch_bounds__(256, 2) attn_kernel(AttnParams p) {
 constexpr int KT2 = 128;                       // keys per barrier
 constexpr int PITCH2 = KT2 * 2 + 8;            // bytes per V^T row: 66 dwords -> conflict-free ds_read_b64
 
-// __launch_bounds__(256, 2): with a 256-register ceiling hipcc keeps MFMA results in VGPRs.  Without it the score tile and
-// the output accumulator shared one AGPR block and every key tile paid 16 v_accvgpr_read + 32 v_accvgpr_write (ISA count),
-// a third of the VALU slots of this VALU-issue-bound loop.
+// __launch_bounds__(256, 3) (second argument: waves per SIMD): with a register ceiling <= 256 hipcc keeps MFMA results in VGPRs.
+// Without it the score tile and the output accumulator shared one AGPR block and every key tile paid 16 v_accvgpr_read + 32
+// v_accvgpr_write (ISA count), a third of the VALU slots of this VALU-bound loop.  3 waves/SIMD = 168 registers: the two query
+// blocks need 171 unconstrained, the cap costs one 8-byte spill outside the key loop and is 12 % faster than 2 waves/SIMD.
 template <int QB>
-__global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
+__global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char vt[32 * PITCH2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int N = p.N;
@@ -207,10 +208,22 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
         if (h == 0) qb[j] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qc * cs + p.qoff);
     }
     f32x16 oacc[QB];
-    float m_run[QB], l_run[QB];
+    // Row sums ride on the matrix core as well: a 16x16x32 MFMA with a 0/1 selector as A and the probability fragment (the PV
+    // MFMA's B operand, reinterpreted) as B.  Lane (r, h) of the 32x32 layout is column r & 15, k-group 2h + (r >> 4) of the
+    // 16x16x32 layout, so selector row 0 = ones on k-groups {0, 2} sums queries 0..15 and row 1 = ones on {1, 3} sums queries
+    // 16..31: lacc[j][0] / [1] in lanes 0..15 hold the running denominators of queries n / n + 16.  (The sums are then taken
+    // over the same bf16-rounded probabilities that enter the numerator.)
+    bf16x8 sel = {};
+    {
+        const int m = lane & 15, kg = lane >> 4;
+        const bf16_t one = (bf16_t)1.f;
+        if ((m == 0 && (kg & 1) == 0) || (m == 1 && (kg & 1) == 1)) sel = bf16x8{one, one, one, one, one, one, one, one};
+    }
+    f32x4 lacc[QB];
+    float m_run[QB];
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
-        m_run[j] = 0.f; l_run[j] = 0.f;              // the first key tile sets m_run unconditionally (first = true)
+        m_run[j] = 0.f; lacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};   // the first key tile sets m_run unconditionally (first = true)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[j][e] = 0.f;
     }
@@ -268,7 +281,8 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
             for (int j = 0; j < QB; ++j) {
                 const float delta = first ? mx[j] : fmaxf(mx[j], 0.f);
                 const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // first tile: l_run = oacc = 0, and exp2(-delta) may be +inf
-                l_run[j] *= alpha;
+                lacc[j][0] *= alpha;                                   // lanes 0..15: query n is this lane's own query ...
+                lacc[j][1] *= __shfl(alpha, (lane + 16) & 63);        // ... and query n + 16 is lane n + 16's
 #pragma unroll
                 for (int e = 0; e < 16; ++e) oacc[j][e] *= alpha;
 #pragma unroll
@@ -282,13 +296,11 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
                 }
             }
         }
-        // phase C (both blocks interleavable): probabilities, row sums, O^T += V^T . P^T
+        // phase C (both blocks interleavable): probabilities; O^T += V^T . P^T and the row sums on the matrix core
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
-            float psum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[j][i] = __builtin_amdgcn_exp2f(s[j][i]); psum += s[j][i]; }
-            l_run[j] += psum;
+            for (int i = 0; i < 16; ++i) s[j][i] = __builtin_amdgcn_exp2f(s[j][i]);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -302,21 +314,24 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[j][8 * ks + e];
                 oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[j], 0, 0, 0);
+                lacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pf, lacc[j], 0, 0, 0);
             }
         }
     };
 
     for (int k0 = 0; k0 < N; k0 += KT2) {
         __syncthreads();
-        {
-            const int ka = k0 + 2 * kp, kbb = ka + 1;
+#pragma unroll
+        for (int part = 0; part < KT2 / 128; ++part) {
+            const int ka = k0 + part * 128 + 2 * kp, kbb = ka + 1;
+            if (ka - 2 * kp >= N) break;                  // this 128-key part lies wholly beyond the keys (workgroup-uniform)
             const bf16x8 va = *reinterpret_cast<const bf16x8*>(base + (int64_t)(ka < N ? ka : N - 1) * cs + p.voff + oct * 8);
             const bf16x8 vb = *reinterpret_cast<const bf16x8*>(base + (int64_t)(kbb < N ? kbb : N - 1) * cs + p.voff + oct * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
                 bf16x2 pr = {va[e], vb[e]};
-                *reinterpret_cast<bf16x2*>(vt + (oct * 8 + e) * PITCH2 + kp * 4) = pr;
+                *reinterpret_cast<bf16x2*>(vt + (oct * 8 + e) * PITCH2 + (part * 64 + kp) * 4) = pr;
             }
         }
         __syncthreads();
@@ -332,7 +347,8 @@ __global__ void __launch_bounds__(256, 2) attn_bf16_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
-        const float inv = 1.f / (l_run[j] + xhalf(l_run[j]));
+        const float l0 = __shfl(lacc[j][0], r & 15), l1 = __shfl(lacc[j][1], r & 15);
+        const float inv = 1.f / ((r >> 4) ? l1 : l0);
         if (qi[j] < N) {
             bf16_t* op = reinterpret_cast<bf16_t*>(p.o) + ((int64_t)b * N + qi[j]) * p.o_cs + p.o_coff;
 #pragma unroll
