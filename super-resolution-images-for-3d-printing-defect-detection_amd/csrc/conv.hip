@@ -349,6 +349,12 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
     const int nct = nb / w.NT, ntap = KS * KS;
     w.thin = Cin <= E;
     w.rows = (dtype == SR_DTYPE_BF16 && KS == 3 && !w.thin) ? 1 : 0;
+    // bf16 1x1 with the whole weight matrix in 16 register fragments: the streaming kernel of conv_pw.hip (same fragment layout)
+    {   // (register budget of the instantiations in conv_pw.hip: 4 waves/SIMD without spills)
+        const int nb16 = round_up(Cout, 16) / 16, nch = round_up(Cin, 32) / 32;
+        w.pw = (dtype == SR_DTYPE_BF16 && KS == 1 && !w.thin && nch <= 4 &&
+                (nb16 <= 2 || (nb16 == 3 && nch <= 3) || (nb16 == 4 && nch == 1))) ? 1 : 0;
+    }
     if (!w.thin && KS == 9) return ctx->fail(SR_ERR_INVALID, "conv: 9x9 supported for <= one 16-byte channel slice only");
     std::vector<char> host;
     auto put = [&](size_t idx, float v) {
@@ -359,19 +365,19 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
         if (tap >= ntap || ci >= Cin || co >= Cout) return 0.f;
         return hwio[((size_t)tap * Cin + ci) * Cout + co];
     };
-    if (w.rows) {
+    if (w.rows || w.pw) {
         w.CoutP = round_up(Cout, 16);
         const int nb16 = w.CoutP / 16;
-        w.NT = (nb16 % 4 == 0) ? 4 : (nb16 % 2 == 0 ? 2 : 1);
+        w.NT = w.pw ? nb16 : ((nb16 % 4 == 0) ? 4 : (nb16 % 2 == 0 ? 2 : 1));
         const int nct16 = nb16 / w.NT;
         w.KGPT = 1;
         w.CinP = round_up(Cin, 32);
         w.nchunks = w.CinP / 32;
-        host.assign((size_t)nct16 * w.nchunks * 9 * w.NT * 1024, 0);
+        host.assign((size_t)nct16 * w.nchunks * ntap * w.NT * 1024, 0);
         size_t idx = 0;
         for (int ct = 0; ct < nct16; ++ct)
             for (int ch = 0; ch < w.nchunks; ++ch)
-                for (int tap = 0; tap < 9; ++tap)
+                for (int tap = 0; tap < ntap; ++tap)
                     for (int n = 0; n < w.NT; ++n)
                         for (int lane = 0; lane < 64; ++lane)
                             for (int j = 0; j < 8; ++j, ++idx)
@@ -448,6 +454,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     for (const TensorView* v : {(const TensorView*)&x, (const TensorView*)&yv, &ep.skip1, &ep.skip2})
         if (v->p && v->blk && (v->cs % 32 != 0 || v->coff % 32 != 0)) return ctx->fail(SR_ERR_INVALID, "conv: a row-blocked view needs 32-channel granularity");
     const bool any_blk = x.blk || yv.blk || (ep.skip1.p && ep.skip1.blk) || (ep.skip2.p && ep.skip2.blk);
+    if (w.pw && r > 1) return ctx->fail(SR_ERR_INVALID, "conv: 1x1 with depth_to_space is not built");
     if (any_blk && !w.rows) return ctx->fail(SR_ERR_INVALID, "conv: only the bf16 3x3 kernel handles row-blocked views");
     if (yv.blk && r > 1) return ctx->fail(SR_ERR_INVALID, "conv: depth_to_space writes NHWC only");
     ConvParams p;
@@ -481,7 +488,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     int rec = -1;
     if (ctx->prof) {
         char nm[96];
-        snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.rows ? "rows" : (w.thin ? "thin" : "wide"),
+        snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),
                  w.dtype == SR_DTYPE_BF16 ? "bf16" : "f32", w.KS, w.KGPT, w.NT);
         const double px = (double)B * H * W;
         double bytes = px * ((double)w.Cin * esz + (double)w.Cout * osz);
@@ -489,7 +496,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         if (p.s2) bytes += px * w.Cout * esz;
         rec = ctx->prof_open(nm, 2.0 * px * w.KS * w.KS * w.Cin * w.Cout, bytes, st);
     }
-    const int rc = w.rows ? conv_rows_launch(ctx, w, p, st)
+    const int rc = w.rows ? conv_rows_launch(ctx, w, p, st) : w.pw ? conv_pw_launch(ctx, w, p, st)
                           : ((w.dtype == SR_DTYPE_BF16) ? dispatch<bf16_t>(ctx, w, p, nct, st) : dispatch<float>(ctx, w, p, nct, st));
     ctx->prof_close(rec, st);
     return rc;

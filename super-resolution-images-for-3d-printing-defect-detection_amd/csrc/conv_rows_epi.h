@@ -31,7 +31,7 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
 
     // ---- skip values are loaded a row group at a time, ahead of that group's stores: the whole tile at once, or two
     //      halves where both skips are present and the register budget is the 3-workgroups-per-CU one (NB16 <= 2)
-    constexpr int RG = (HAS1 && HAS2 && NB16 <= 2) ? R / 2 : R;
+    constexpr int RG = (HAS1 && HAS2 && NB16 <= 2 && R >= 2) ? R / 2 : R;
     int cc[NB16];
 #pragma unroll
     for (int n = 0; n < NB16; ++n) cc[n] = min((ct * NB16 + n) * 16 + 4 * q, p.Cout - 4);
@@ -123,16 +123,26 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     }
 }
 
-// Dispatch: slow generic path (odd channel counts / unaligned views / tanh: the final RGB conv) or one fast variant.
-// The host passes a lone skip as s1 (conv_launch swaps), so "s2 only" does not occur.
-template <int NB16, int R>
-__device__ __forceinline__ void rows_epilogue(const ConvParams& p, f32x4 (&acc)[R][NB16], const f32x4 (&biasv)[NB16], int b, int y0, int x0,
-                                              int ct, int wave, int px, int q) {
-    const int H = p.H, W = p.W;
+// Which epilogue a launch takes (wave-uniform, fixed for the whole kernel): -1 = the generic per-element path (odd channel counts /
+// unaligned views / tanh: the final RGB conv), else 2*skips + pair with skips = 0 (none), 1 (skip 1), 2 (both) and pair = 16-byte
+// paired stores.  The host passes a lone skip as s1 (conv_launch swaps), so "s2 only" does not occur.
+template <int NB16>
+__device__ __forceinline__ int rows_epilogue_kind(const ConvParams& p) {
     const int Cd = p.Cd, rr_ = p.r;
     const bool has1 = p.s1 != nullptr, has2 = p.s2 != nullptr;
     const bool fast = p.vec != 0 && (p.Cout & 3) == 0 && p.act != SR_ACT_TANH && (rr_ <= 1 || (Cd & 15) == 0) && (has1 || !has2);
-    if (!fast) {
+    if (!fast) return -1;
+    const bool pair_ok = NB16 >= 2 && p.out_f32 == 0 && (rr_ <= 1 || (Cd & 31) == 0) && (p.Cout & 31) == 0;
+    return 2 * (has2 ? 2 : (has1 ? 1 : 0)) + (pair_ok ? 1 : 0);
+}
+
+// One epilogue, chosen at compile time (a kernel that runs the epilogue inside a loop instantiates its loop per KIND, so that
+// only that variant's loop invariants stay live).
+template <int NB16, int R, int KIND>
+__device__ __forceinline__ void rows_epilogue_as(const ConvParams& p, f32x4 (&acc)[R][NB16], const f32x4 (&biasv)[NB16], int b, int y0, int x0,
+                                                 int ct, int wave, int px, int q) {
+    if constexpr (KIND < 0) {
+        const int H = p.H, W = p.W;
         const int ox = x0 + px;
         const int oyw = y0 + wave * R;
         if (ox < W) {
@@ -147,18 +157,25 @@ __device__ __forceinline__ void rows_epilogue(const ConvParams& p, f32x4 (&acc)[
                 }
             }
         }
-        return;
+    } else {
+        constexpr bool PAIR = (KIND & 1) != 0 && NB16 >= 2;
+        rows_epilogue_fast<NB16, R, (KIND >> 1) >= 1, (KIND >> 1) >= 2, PAIR>(p, acc, biasv, b, y0, x0, ct, wave, px, q);
     }
-    const bool pair_ok = NB16 >= 2 && p.out_f32 == 0 && (rr_ <= 1 || (Cd & 31) == 0) && (p.Cout & 31) == 0;
-#define SR_EPI(H1, H2)                                                                                             \
-    do {                                                                                                           \
-        if (NB16 >= 2 && pair_ok) rows_epilogue_fast<NB16, R, H1, H2, (NB16 >= 2)>(p, acc, biasv, b, y0, x0, ct, wave, px, q); \
-        else rows_epilogue_fast<NB16, R, H1, H2, false>(p, acc, biasv, b, y0, x0, ct, wave, px, q);                \
-    } while (0)
-    if (has2) SR_EPI(true, true);
-    else if (has1) SR_EPI(true, false);
-    else SR_EPI(false, false);
-#undef SR_EPI
+}
+
+// Run-time dispatch over the kinds (one-shot use at the end of a tile kernel).
+template <int NB16, int R>
+__device__ __forceinline__ void rows_epilogue(const ConvParams& p, f32x4 (&acc)[R][NB16], const f32x4 (&biasv)[NB16], int b, int y0, int x0,
+                                              int ct, int wave, int px, int q) {
+    switch (rows_epilogue_kind<NB16>(p)) {
+        case -1: rows_epilogue_as<NB16, R, -1>(p, acc, biasv, b, y0, x0, ct, wave, px, q); break;
+        case 0: rows_epilogue_as<NB16, R, 0>(p, acc, biasv, b, y0, x0, ct, wave, px, q); break;
+        case 1: rows_epilogue_as<NB16, R, 1>(p, acc, biasv, b, y0, x0, ct, wave, px, q); break;
+        case 2: rows_epilogue_as<NB16, R, 2>(p, acc, biasv, b, y0, x0, ct, wave, px, q); break;
+        case 3: rows_epilogue_as<NB16, R, 3>(p, acc, biasv, b, y0, x0, ct, wave, px, q); break;
+        case 4: rows_epilogue_as<NB16, R, 4>(p, acc, biasv, b, y0, x0, ct, wave, px, q); break;
+        default: rows_epilogue_as<NB16, R, 5>(p, acc, biasv, b, y0, x0, ct, wave, px, q); break;
+    }
 }
 
 }  // namespace convk

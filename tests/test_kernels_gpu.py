@@ -37,7 +37,10 @@ CONV_CASES = [
     (1, 7, 5, 72, 8, 3, "relu"),         # G=8 growth conv (Cin not a multiple of the chunk)
     (1, 16, 16, 64, 3, 3, "tanh"),       # final conv
     (1, 6, 6, 512, 512, 3, "relu"),      # VGG block5
-    (1, 9, 11, 64, 48, 1, "linear"),     # attention projection
+    (1, 9, 11, 64, 48, 1, "linear"),     # attention projection (streaming 1x1 kernel: 3 cout blocks x 2 chunks)
+    (1, 13, 21, 32, 64, 1, "linear"),    # attention output conv (4 cout blocks x 1 chunk), ragged 16-pixel segments
+    (2, 7, 40, 128, 16, 1, "lrelu"),     # 1x1, 1 cout block x 4 chunks
+    (1, 5, 5, 160, 64, 1, "relu"),       # 1x1 too wide for the register-resident kernel: first-generation path
 ]
 
 
@@ -75,6 +78,23 @@ def test_conv2d_epilogue_skips_clip(ctx, dtype):
     got = ctx.conv2d(_dev(ctx, x, td), w, b, alpha=0.04, skip1=_dev(ctx, s1, td), beta1=1.0, skip2=_dev(ctx, s2, td), beta2=0.2,
                      clip01=True).float().cpu().numpy()
     assert rel_l2(got, ref) <= (1e-5 if dtype == "f32" else 1e-2)
+
+
+def test_conv1x1_with_skips(ctx):
+    """SelfAttention tail: y = conv1x1(o) + x (ESRGAN_model.py:66-69) on the streaming 1x1 kernel, one and two skips."""
+    rng = np.random.default_rng(17)
+    B, H, W = 2, 11, 37
+    o = round_to_bf16(rng.standard_normal((B, H, W, 32)).astype(np.float32))
+    s1 = round_to_bf16(rng.standard_normal((B, H, W, 64)).astype(np.float32))
+    s2 = round_to_bf16(rng.standard_normal((B, H, W, 64)).astype(np.float32))
+    w = round_to_bf16((rng.standard_normal((1, 1, 32, 64)) / 6).astype(np.float32))
+    b = rng.uniform(-0.1, 0.1, 64).astype(np.float32)
+    conv = O.conv2d(o, w, b, dtype=np.float64)
+    od, d1, d2 = (_dev(ctx, a, torch.bfloat16) for a in (o, s1, s2))
+    got1 = ctx.conv2d(od, w, b, skip1=d1, beta1=1.0).float().cpu().numpy()
+    assert rel_l2(got1, conv + s1) <= 1e-2
+    got2 = ctx.conv2d(od, w, b, alpha=0.5, skip1=d1, beta1=1.0, skip2=d2, beta2=0.2).float().cpu().numpy()
+    assert rel_l2(got2, 0.5 * conv + s1 + 0.2 * s2) <= 1e-2
 
 
 @pytest.mark.parametrize("which", [1, 2])
