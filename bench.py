@@ -59,13 +59,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunk", type=int, default=1764, help="patches per sr_forward call (Keras predict chunking: result-invariant)")
-    ap.add_argument("--tiles-per-call", type=int, default=4, help="LR tiles whose patches share the generator launches")
+    ap.add_argument("--chunk", type=int, default=0, help="patches per sr_forward call (Keras predict chunking: result-invariant); 0 = all patches of a call")
+    ap.add_argument("--tiles-per-call", type=int, default=16,
+                    help="LR tiles whose patches share the generator launches (16 = the whole per-GPU batch: 7056 patches, ~115 GB of workspace)")
     ap.add_argument("--streams", type=int, default=1, help="independent HIP streams (one generator instance each) the tiles are dealt to")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass (no roofline object)")
     ap.add_argument("--no-attention", action="store_true", help="non-reference graph, kernel tuning only")
     args = ap.parse_args()
+    if args.chunk <= 0:
+        args.chunk = 441 * max(1, args.tiles_per_call)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
