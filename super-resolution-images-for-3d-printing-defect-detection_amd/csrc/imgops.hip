@@ -145,6 +145,58 @@ __global__ void bicubic_f32_kernel(const float* x, int B, int H, int W, int C, i
 }
 
 // uint8 fixed-point path: 11-bit coefficients, int accumulation, rounding >> 22, saturate.
+// Tiled variant for fp32 -> fp32 with a dense output (y_cs == C): a block produces BT_Y x BT_X output pixels from an LDS copy of
+// the source window they touch (for up-scaling a few rows x a few dozen columns), and writes its rows back as consecutive
+// floats.  The per-pixel kernel above issues 16*C scattered 4-byte global loads per output pixel and is bound by the load
+// issue rate (0.7 TB/s of its 4x up-scale stream); here global loads and stores are both row-contiguous.  Same arithmetic,
+// same summation order as above.  The host picks this kernel when the window fits BT_WIN floats.
+constexpr int BT_X = 64, BT_Y = 4, BT_WIN = 6144;
+__global__ void __launch_bounds__(256) bicubic_f32_tile_kernel(const float* x, int H, int W, int C, int oH, int oW, double sy, double sx, float* y) {
+    __shared__ float win[BT_WIN];
+    __shared__ float outt[BT_Y * BT_X * 4];
+    const int tid = threadIdx.x, tx = tid & (BT_X - 1), ty = tid / BT_X;
+    const int ox0 = blockIdx.x * BT_X, oy0 = blockIdx.y * BT_Y, b = blockIdx.z;
+    const int oxl = min(ox0 + BT_X, oW) - 1, oyl = min(oy0 + BT_Y, oH) - 1;       // last pixel of the tile
+    int ia[4], ib[4];
+    float wdummy[4];
+    cubic_axis(ox0, sx, W, ia, wdummy); cubic_axis(oxl, sx, W, ib, wdummy);
+    const int ix0 = ia[0], nx = ib[3] - ia[0] + 1;                                 // clamped indices are monotonic in the output index
+    cubic_axis(oy0, sy, H, ia, wdummy); cubic_axis(oyl, sy, H, ib, wdummy);
+    const int iy0 = ia[0], ny = ib[3] - ia[0] + 1;
+    const float* xb = x + (int64_t)b * H * W * C;
+    const int rowlen = nx * C;
+    for (int i = tid; i < ny * rowlen; i += 256) {
+        const int r = i / rowlen, k = i - r * rowlen;
+        win[i] = xb[((int64_t)(iy0 + r) * W + ix0) * C + k];
+    }
+    __syncthreads();
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    if (ox < oW && oy < oH) {
+        int ix[4], iy[4];
+        float wx[4], wy[4];
+        cubic_axis(ox, sx, W, ix, wx);
+        cubic_axis(oy, sy, H, iy, wy);
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const float* row = win + (iy[ky] - iy0) * rowlen + c;
+                float hsum = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) hsum += row[(ix[kx] - ix0) * C] * wx[kx];
+                acc += hsum * wy[ky];
+            }
+            outt[(ty * BT_X + tx) * C + c] = acc;
+        }
+    }
+    __syncthreads();
+    const int ncols = (min(ox0 + BT_X, oW) - ox0) * C;                             // floats per tile row
+    for (int i = tid; i < BT_Y * BT_X * C; i += 256) {
+        const int r = i / (BT_X * C), k = i - r * (BT_X * C);
+        if (oy0 + r < oH && k < ncols) y[(((int64_t)b * oH + oy0 + r) * oW + ox0) * C + k] = outt[r * BT_X * C + k];
+    }
+}
+
 __global__ void bicubic_u8_kernel(const uint8_t* x, int B, int H, int W, int C, int oH, int oW, double sy, double sx, uint8_t* y) {
     const int64_t n = (int64_t)B * oH * oW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -391,7 +443,13 @@ int bicubic_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, i
     // OpenCV: inv_scale = dsize/ssize (double), scale = 1./inv_scale
     const double sy = 1.0 / ((double)outH / (double)H), sx = 1.0 / ((double)outW / (double)W);
     const int64_t n = (int64_t)B * outH * outW;
-    if (dtype == SR_DTYPE_F32)
+    // source window of a BT_Y x BT_X output tile: (tile extent * scale + 4 taps + 1) per axis
+    const int64_t win = (int64_t)((int)(BT_X * sx) + 6) * ((int)(BT_Y * sy) + 6) * C;
+    if (dtype == SR_DTYPE_F32 && out_dtype == SR_DTYPE_F32 && y_cs == C && C <= 4 && win <= BT_WIN && B <= 65535 &&
+        (outH + BT_Y - 1) / BT_Y <= 65535)
+        hipLaunchKernelGGL(bicubic_f32_tile_kernel, dim3((outW + BT_X - 1) / BT_X, (outH + BT_Y - 1) / BT_Y, B), dim3(256), 0, st,
+                           static_cast<const float*>(x), H, W, C, outH, outW, sy, sx, static_cast<float*>(y));
+    else if (dtype == SR_DTYPE_F32)
         hipLaunchKernelGGL(bicubic_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const float*>(x), B, H, W, C, outH, outW,
                            sy, sx, y, out_dtype, y_cs);
     else if (dtype == SR_DTYPE_U8)

@@ -199,7 +199,10 @@ def test_self_attention_large_uniform_scores(ctx, sign, dtype):
 
 # ------------------------------------------------------------------------------------------------ image ops
 @pytest.mark.parametrize("shape,out", [((1, 64, 64, 3), (256, 256)), ((2, 23, 31, 3), (46, 62)), ((1, 239, 239, 3), (478, 478)),
-                                       ((1, 10, 10, 1), (37, 23))])
+                                       ((1, 10, 10, 1), (37, 23)),
+                                       ((2, 40, 40, 3), (30, 30)),      # mild down-scale: still the LDS-window kernel
+                                       ((1, 64, 64, 3), (16, 16)),      # 4x down-scale: window too large, per-pixel kernel
+                                       ((1, 3, 5, 3), (130, 70))])      # tiny source, every tap clamped somewhere
 def test_bicubic_f32(ctx, shape, out):
     rng = np.random.default_rng(3)
     x = rng.uniform(0, 1, shape).astype(np.float32)
