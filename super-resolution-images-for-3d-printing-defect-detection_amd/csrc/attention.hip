@@ -23,7 +23,7 @@ namespace {
 constexpr int KV_TILE = 64;
 
 template <typename T> struct AT;
-template <> struct AT<bf16_t> { static constexpr int PITCH = KV_TILE * 2 + 8; };    // bytes per V^T row in LDS
+template <> struct AT<bf16_t> { [[maybe_unused]] static constexpr int PITCH = KV_TILE * 2 + 8; };    // bytes per V^T row in LDS
 template <> struct AT<float>  { static constexpr int PITCH = KV_TILE * 4 + 4; };
 
 struct AttnParams {

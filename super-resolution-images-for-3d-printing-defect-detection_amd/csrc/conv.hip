@@ -176,7 +176,6 @@ constexpr int THIN_GPS = 16;   // k-groups per weight stage
 template <typename T, int KS, int NT, int MT>
 __global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
     typedef typename TT<T>::frag frag;
-    constexpr int E = TT<T>::E;
     constexpr int TH = 8 * MT, TW = 16;
     constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PADK = (KS - 1) / 2, NTAP = KS * KS;
     constexpr int KGT = (NTAP + 1) / 2;
