@@ -83,6 +83,22 @@ def test_esrgan_generator_forward(ctx, scale, G, nb, att, dtype):
         assert O.psnr((got + 1) / 2, (ref + 1) / 2, dtype=np.float64).min() >= 38.0
 
 
+@pytest.mark.parametrize("hw", [(19, 37), (5, 3), (48, 17)])
+def test_esrgan_row_blocked_buffers_ragged_shapes(ctx, hw):
+    """bf16 with G = 32 keeps the concat buffers row-blocked ([B][H][C/32][W][32], csrc/conv_common.h): image sizes that are not
+    multiples of the 16x16 / 12x16 tiles, narrower than one tile, and a batch of 3 -- against the fp64 oracle."""
+    H, W = hw
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, num_blocks=1, growth_channels=32, use_attention=False, ctx=ctx)
+    w = init_weights(m.layer_shapes(), seed=3200)
+    x = np.random.default_rng(5).uniform(-1, 1, (3, H, W, 3)).astype(np.float32)
+    w, x = prep(w, x, "bf16")
+    ref = M.esrgan_g_forward(x, w, 2, 1, dtype=np.float64, attention=False)
+    got = run(ctx, m, w, x, "bf16")
+    assert got.shape == ref.shape == (3, 2 * H, 2 * W, 3)
+    assert rel_l2(got, ref) <= 3e-2
+    assert np.array_equal(got, run(ctx, m, w, x, "bf16"))      # same buffers, second call: same image
+
+
 def test_esrgan_predict_chunking_invariant(ctx):
     """keras predict(batch_size) chunking must not change results (no batch-coupled op)."""
     m = Model("esrgan_g", compute_dtype="f32", scale_factor=2, num_blocks=1, growth_channels=8, ctx=ctx)
