@@ -145,16 +145,20 @@ __global__ void bicubic_f32_kernel(const float* x, int B, int H, int W, int C, i
 }
 
 // uint8 fixed-point path: 11-bit coefficients, int accumulation, rounding >> 22, saturate.
-// Tiled variant for fp32 -> fp32 with a dense output (y_cs == C): a block produces BT_Y x BT_X output pixels from an LDS copy of
-// the source window they touch (for up-scaling a few rows x a few dozen columns), and writes its rows back as consecutive
-// floats.  The per-pixel kernel above issues 16*C scattered 4-byte global loads per output pixel and is bound by the load
-// issue rate (0.7 TB/s of its 4x up-scale stream); here global loads and stores are both row-contiguous.  Same arithmetic,
-// same summation order as above.  The host picks this kernel when the window fits BT_WIN floats.
-constexpr int BT_X = 64, BT_Y = 4, BT_WIN = 6144;
-__global__ void __launch_bounds__(256) bicubic_f32_tile_kernel(const float* x, int H, int W, int C, int oH, int oW, double sy, double sx, float* y) {
-    __shared__ float win[BT_WIN];
-    __shared__ float outt[BT_Y * BT_X * 4];
-    const int tid = threadIdx.x, tx = tid & (BT_X - 1), ty = tid / BT_X;
+// Tiled variant for fp32 -> fp32 with a dense output (y_cs == C).  A block produces BT_Y rows x BT_X columns from an LDS copy of
+// the source window they touch; a thread owns one output column: its horizontal 4-tap sums over the window rows are computed
+// once (cv2 is separable: horizontal then vertical, so sharing them across output rows is the same arithmetic in the same order)
+// and parked in LDS, then every output row of the tile is 4 vertical taps per channel.  Rows go back to memory as consecutive
+// floats.  The per-pixel kernel above issues 16*C scattered 4-byte global loads and ~250 instructions per output pixel (index
+// arithmetic included) and is instruction-bound at 0.7 TB/s of its 4x up-scale stream.  The host picks this kernel when the
+// window and the row sums fit the LDS arrays.
+constexpr int BT_X = 256, BT_Y = 8, BT_WIN = 6144, BT_ROWS = 12;
+__global__ void __launch_bounds__(256) bicubic_f32_tile_kernel(const float* x, int H, int W, int C, int oH, int oW, double sy, double sx, float* y,
+                                                               int win_floats) {
+    extern __shared__ float bt_smem[];
+    float* win = bt_smem;                               // source window [ny][nx][C] (win_floats, host-sized upper bound)
+    float* hs = bt_smem + win_floats;                   // horizontal sums [ny][BT_X][C]; later the output tile [BT_Y][BT_X*C]
+    const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * BT_X, oy0 = blockIdx.y * BT_Y, b = blockIdx.z;
     const int oxl = min(ox0 + BT_X, oW) - 1, oyl = min(oy0 + BT_Y, oH) - 1;       // last pixel of the tile
     int ia[4], ib[4];
@@ -165,35 +169,60 @@ __global__ void __launch_bounds__(256) bicubic_f32_tile_kernel(const float* x, i
     const int iy0 = ia[0], ny = ib[3] - ia[0] + 1;
     const float* xb = x + (int64_t)b * H * W * C;
     const int rowlen = nx * C;
-    for (int i = tid; i < ny * rowlen; i += 256) {
-        const int r = i / rowlen, k = i - r * rowlen;
-        win[i] = xb[((int64_t)(iy0 + r) * W + ix0) * C + k];
+    for (int r = 0; r < ny; ++r) {
+        const float* src = xb + ((int64_t)(iy0 + r) * W + ix0) * C;
+        for (int k = tid; k < rowlen; k += 256) win[r * rowlen + k] = src[k];
+    }
+    __shared__ int yrow[BT_Y][4];                        // the vertical taps are the same for every column: one thread per row
+    __shared__ float ywt[BT_Y][4];
+    if (tid < BT_Y) {
+        int iy[4];
+        float wy[4];
+        cubic_axis(min(oy0 + tid, oH - 1), sy, H, iy, wy);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { yrow[tid][k] = (iy[k] - iy0) * BT_X; ywt[tid][k] = wy[k]; }
     }
     __syncthreads();
-    const int ox = ox0 + tx, oy = oy0 + ty;
-    if (ox < oW && oy < oH) {
-        int ix[4], iy[4];
-        float wx[4], wy[4];
+    const int ox = ox0 + tid;
+    if (ox < oW) {
+        int ix[4];
+        float wx[4];
         cubic_axis(ox, sx, W, ix, wx);
-        cubic_axis(oy, sy, H, iy, wy);
-        for (int c = 0; c < C; ++c) {
-            float acc = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const float* row = win + (iy[ky] - iy0) * rowlen + c;
+        const int o0 = (ix[0] - ix0) * C, o1 = (ix[1] - ix0) * C, o2 = (ix[2] - ix0) * C, o3 = (ix[3] - ix0) * C;
+        for (int r = 0; r < ny; ++r) {
+            const float* row = win + r * rowlen;
+            for (int c = 0; c < C; ++c) {
                 float hsum = 0.f;
-#pragma unroll
-                for (int kx = 0; kx < 4; ++kx) hsum += row[(ix[kx] - ix0) * C] * wx[kx];
-                acc += hsum * wy[ky];
+                hsum += row[o0 + c] * wx[0]; hsum += row[o1 + c] * wx[1]; hsum += row[o2 + c] * wx[2]; hsum += row[o3 + c] * wx[3];
+                hs[(r * BT_X + tid) * C + c] = hsum;
             }
-            outt[(ty * BT_X + tx) * C + c] = acc;
         }
     }
+    // a column's sums are read back only by the thread that wrote them: no barrier needed before the vertical pass
+    float outv[BT_Y][4];
+#pragma unroll
+    for (int ty = 0; ty < BT_Y; ++ty) {
+        const int oy = oy0 + ty;
+        if (ox < oW && oy < oH) {
+            for (int c = 0; c < C; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) acc += hs[(yrow[ty][ky] + tid) * C + c] * ywt[ty][ky];
+                outv[ty][c] = acc;
+            }
+        }
+    }
+    __syncthreads();                                     // everyone is done with hs: reuse it for the output tile
+#pragma unroll
+    for (int ty = 0; ty < BT_Y; ++ty)
+        for (int c = 0; c < C; ++c) hs[(ty * BT_X + tid) * C + c] = outv[ty][c];
     __syncthreads();
     const int ncols = (min(ox0 + BT_X, oW) - ox0) * C;                             // floats per tile row
-    for (int i = tid; i < BT_Y * BT_X * C; i += 256) {
-        const int r = i / (BT_X * C), k = i - r * (BT_X * C);
-        if (oy0 + r < oH && k < ncols) y[(((int64_t)b * oH + oy0 + r) * oW + ox0) * C + k] = outt[r * BT_X * C + k];
+#pragma unroll
+    for (int r = 0; r < BT_Y; ++r) {
+        if (oy0 + r >= oH) break;
+        float* dst = y + (((int64_t)b * oH + oy0 + r) * oW + ox0) * C;
+        for (int k = tid; k < ncols; k += 256) dst[k] = hs[r * BT_X * C + k];
     }
 }
 
@@ -444,11 +473,12 @@ int bicubic_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, i
     const double sy = 1.0 / ((double)outH / (double)H), sx = 1.0 / ((double)outW / (double)W);
     const int64_t n = (int64_t)B * outH * outW;
     // source window of a BT_Y x BT_X output tile: (tile extent * scale + 4 taps + 1) per axis
-    const int64_t win = (int64_t)((int)(BT_X * sx) + 6) * ((int)(BT_Y * sy) + 6) * C;
-    if (dtype == SR_DTYPE_F32 && out_dtype == SR_DTYPE_F32 && y_cs == C && C <= 4 && win <= BT_WIN && B <= 65535 &&
+    const int64_t win_rows = (int)(BT_Y * sy) + 6, win = (int64_t)((int)(BT_X * sx) + 6) * win_rows * C;
+    if (dtype == SR_DTYPE_F32 && out_dtype == SR_DTYPE_F32 && y_cs == C && C <= 4 && win <= BT_WIN && win_rows <= BT_ROWS && B <= 65535 &&
         (outH + BT_Y - 1) / BT_Y <= 65535)
-        hipLaunchKernelGGL(bicubic_f32_tile_kernel, dim3((outW + BT_X - 1) / BT_X, (outH + BT_Y - 1) / BT_Y, B), dim3(256), 0, st,
-                           static_cast<const float*>(x), H, W, C, outH, outW, sy, sx, static_cast<float*>(y));
+        hipLaunchKernelGGL(bicubic_f32_tile_kernel, dim3((outW + BT_X - 1) / BT_X, (outH + BT_Y - 1) / BT_Y, B), dim3(256),
+                           (size_t)(win + (win_rows > BT_Y ? win_rows : BT_Y) * BT_X * C) * sizeof(float), st,
+                           static_cast<const float*>(x), H, W, C, outH, outW, sy, sx, static_cast<float*>(y), (int)win);
     else if (dtype == SR_DTYPE_F32)
         hipLaunchKernelGGL(bicubic_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const float*>(x), B, H, W, C, outH, outW,
                            sy, sx, y, out_dtype, y_cs);
