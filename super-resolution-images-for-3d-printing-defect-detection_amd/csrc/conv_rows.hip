@@ -122,12 +122,29 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wpre[i]) : "v"(ptr) : "memory");
         }
     };
+    // Without register prefetch the chunk's weights go global -> LDS by LDS-DMA (global_load_lds_dwordx4; the packed layout is the
+    // LDS layout, 1 KiB per wave-instruction): no VGPR round trip and none of the ds_write_b128 traffic (36 KB per chunk at 64
+    // couts) through the VGPR -> LDS path.  Issued after the barrier that frees the weight buffer, landed by land_all()'s wait.
+    constexpr bool WDMA = !WPRE;
+    auto dma_w = [&](int chunk) {
+        const char* wsrc = wbase + (int64_t)chunk * (WUNITS * 16);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < (WUNITS / 64 + 3) / 4; ++i) {
+            const int piece = wv + 4 * i;                    // wave-uniform
+            if (piece < WUNITS / 64)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ((size_t)piece * 64 + lane) * 16),
+                                                 (__attribute__((address_space(3))) void*)(lw + piece * 1024), 16, 0, 0);
+        }
+    };
     auto land_all = [&]() {   // wait for every asm load in flight; "+v" on each destination orders all their uses behind the wait
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NINT; ++i) asm volatile("" : "+v"(pre[i]));
+        if constexpr (WPRE) {
 #pragma unroll
-        for (int i = 0; i < NWT; ++i) asm volatile("" : "+v"(wpre[i]));
+            for (int i = 0; i < NWT; ++i) asm volatile("" : "+v"(wpre[i]));
+        }
     };
     auto write_w = [&]() {
 #pragma unroll
@@ -159,7 +176,7 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
     for (int chunk = 0; chunk < nch; ++chunk) {
         __syncthreads();
         if (chunk < 6) STAMP_AT(2 + 2 * chunk);
-        if (!WPRE) issue_w(chunk);     // all loads in flight together, one exposed latency per chunk
+        if (WDMA) dma_w(chunk);        // all loads in flight together, one exposed latency per chunk
         land_all();
 #pragma unroll
         for (int i = 0; i < NINT; ++i)
@@ -167,7 +184,7 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
                 bf16x8 z = {};
                 *reinterpret_cast<bf16x8*>(lin + doff[i]) = soff[i] >= 0 ? pre[i] : z;
             }
-        write_w();
+        if (!WDMA) write_w();
         __syncthreads();
         if (chunk < 6) STAMP_AT(3 + 2 * chunk);
         if (chunk + 1 < nch) {
