@@ -176,15 +176,26 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
     for (int chunk = 0; chunk < nch; ++chunk) {
         __syncthreads();
         if (chunk < 6) STAMP_AT(2 + 2 * chunk);
-        if (WDMA) dma_w(chunk);        // all loads in flight together, one exposed latency per chunk
-        land_all();
+        if constexpr (WDMA) {
+            // the weight DMA just issued is younger than the input prefetch (issued a whole compute phase ago): wait for all but
+            // this wave's DMA instructions (vmcnt counts in order), write the input image while the weights are still in flight
+            dma_w(chunk);
+            constexpr int PIECES = WUNITS / 64, Q = PIECES / 4, REM = PIECES % 4;
+            if (REM != 0 && __builtin_amdgcn_readfirstlane(wave) < REM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q) : "memory");
+#pragma unroll
+            for (int i = 0; i < NINT; ++i) asm volatile("" : "+v"(pre[i]));
+        } else {
+            land_all();
+        }
 #pragma unroll
         for (int i = 0; i < NINT; ++i)
             if (doff[i] >= 0) {
                 bf16x8 z = {};
                 *reinterpret_cast<bf16x8*>(lin + doff[i]) = soff[i] >= 0 ? pre[i] : z;
             }
-        if (!WDMA) write_w();
+        if constexpr (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else write_w();
         __syncthreads();
         if (chunk < 6) STAMP_AT(3 + 2 * chunk);
         if (chunk + 1 < nch) {
