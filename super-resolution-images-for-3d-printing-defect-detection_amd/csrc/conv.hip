@@ -345,6 +345,8 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
     const int nb = w.CoutP / 32;
     w.NT = (nb % 2 == 0) ? 2 : (nb % 3 == 0 ? 3 : 1);
     if (KS == 5 && !(Cin <= E)) w.NT = 1;   // 25 taps of weights: keep the LDS stage small
+    if (Cin <= E) w.NT = 1;                  // thin (RGB) inputs: one 32-cout block per workgroup (112 + 48 registers, 3 waves/SIMD);
+                                             // re-reading the 3-channel input per cout block is cheap, 1 wave/SIMD at NT=3 was not (9x9: 1.8x)
     const int nct = nb / w.NT, ntap = KS * KS;
     w.thin = Cin <= E;
     w.rows = (dtype == SR_DTYPE_BF16 && KS == 3 && !w.thin) ? 1 : 0;
