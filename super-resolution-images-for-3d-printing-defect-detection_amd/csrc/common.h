@@ -68,6 +68,7 @@ struct ConvWeights {          // device-resident, MFMA-fragment-ordered (see con
     int KGPT = 2;             // wide: k-groups per tap per stage (2 -> 64 B of channels, 4 -> 128 B)
     int NT = 1;               // 32-wide cout blocks per workgroup (rows variant: 16-wide blocks, NB16)
     int rows = 0;             // 1: bf16 3x3 row-sliding kernel (conv_rows.hip) and its weight layout
+    int few = 0;              // 1: fp32, <= 4 couts: VALU kernel (conv.hip conv_fewcout_f32_kernel), weights [tap][CinP][4]
     int pw = 0;               // 1: bf16 1x1 streaming kernel (conv_pw.hip), same fragment layout, NT = all cout blocks
     int nchunks = 1;          // wide: Cin stages;  thin: unused
     size_t bytes = 0;

@@ -332,6 +332,59 @@ inline uint16_t f32_to_bf16_host(float f) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+// fp32 convs with at most 4 output channels (SRCNN's 5x5 32->3 tail, the fp32 models' RGB tails).  On the 32-cout MFMA tile
+// these compute 32 couts to keep 3 (1.9 ms of SRCNN's 4.9 ms); here a thread owns one output pixel and its <= 4 couts on the
+// VALU: the halo tile of 4 input channels at a time sits in LDS (16 B per pixel, conflict-free ds_read_b128), the weights are
+// wave-uniform and come through the scalar cache ([tap][cin][4] floats), one v_fma per (tap, cin, cout) in a fixed order.
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
+    constexpr int TS = 16, PS = TS + KS - 1, PADK = (KS - 1) / 2;
+    __shared__ __attribute__((aligned(16))) float tile[PS * PS * 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int b = blockIdx.z, y0 = blockIdx.y * TS, x0 = blockIdx.x * TS;
+    const int H = p.H, W = p.W;
+    const float* inb = reinterpret_cast<const float*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;
+    const f32x4* __restrict__ wk = reinterpret_cast<const f32x4*>(p.w);
+    const int CinP = p.nchunks * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c4 = 0; c4 < p.nchunks; ++c4) {
+        __syncthreads();
+        for (int u = tid; u < PS * PS; u += 256) {
+            const int py = u / PS, px = u - py * PS;
+            const int gy = y0 + py - PADK, gx = x0 + px - PADK;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const f32x4*>(inb + ((int64_t)gy * W + gx) * p.in_cs + c4 * 4);
+            *reinterpret_cast<f32x4*>(tile + u * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(tile + ((ty + ky) * PS + tx + kx) * 4);
+                const f32x4* wt = wk + (size_t)(ky * KS + kx) * CinP + c4 * 4;      // wave-uniform
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    const f32x4 wv = wt[ci];
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(xv[ci], wv[co], acc[co]);
+                }
+            }
+    }
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, acc);
+}
+
+template <int KS>
+int launch_fewcout(sr_ctx* ctx, const ConvParams& p, hipStream_t st) {
+    if (p.B > 65535 || (p.H + 15) / 16 > 65535) return ctx->fail(SR_ERR_INVALID, "conv: too many tiles for one launch");
+    hipLaunchKernelGGL(conv_fewcout_f32_kernel<KS>, dim3((p.W + 15) / 16, (p.H + 15) / 16, p.B), dim3(256), 0, st, p);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS, int Cin, int Cout, int dtype,
@@ -349,6 +402,8 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
                                              // re-reading the 3-channel input per cout block is cheap, 1 wave/SIMD at NT=3 was not (9x9: 1.8x)
     const int nct = nb / w.NT, ntap = KS * KS;
     w.thin = Cin <= E;
+    // fp32, <= 4 couts, not thin: the VALU kernel (conv_fewcout_f32_kernel), weights [tap][CinP][4]
+    w.few = (dtype == SR_DTYPE_F32 && Cout <= 4 && !w.thin && (KS == 3 || KS == 5)) ? 1 : 0;
     w.rows = (dtype == SR_DTYPE_BF16 && KS == 3 && !w.thin) ? 1 : 0;
     // bf16 1x1 with the whole weight matrix in 16 register fragments: the streaming kernel of conv_pw.hip (same fragment layout)
     {   // (register budget of the instantiations in conv_pw.hip: 4 waves/SIMD without spills)
@@ -366,7 +421,15 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
         if (tap >= ntap || ci >= Cin || co >= Cout) return 0.f;
         return hwio[((size_t)tap * Cin + ci) * Cout + co];
     };
-    if (w.rows || w.pw) {
+    if (w.few) {
+        w.CoutP = 4; w.NT = 1; w.KGPT = 0;
+        w.CinP = round_up(Cin, 4);
+        w.nchunks = w.CinP / 4;
+        host.assign((size_t)ntap * w.CinP * 4 * sizeof(float), 0);
+        for (int tap = 0; tap < ntap; ++tap)
+            for (int ci = 0; ci < w.CinP; ++ci)
+                for (int co = 0; co < 4; ++co) put(((size_t)tap * w.CinP + ci) * 4 + co, W(tap, ci, co));
+    } else if (w.rows || w.pw) {
         w.CoutP = round_up(Cout, 16);
         const int nb16 = w.CoutP / 16;
         w.NT = w.pw ? nb16 : ((nb16 % 4 == 0) ? 4 : (nb16 % 2 == 0 ? 2 : 1));
@@ -489,7 +552,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     int rec = -1;
     if (ctx->prof) {
         char nm[96];
-        snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),
+        snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.few ? "few" : w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),
                  w.dtype == SR_DTYPE_BF16 ? "bf16" : "f32", w.KS, w.KGPT, w.NT);
         const double px = (double)B * H * W;
         double bytes = px * ((double)w.Cin * esz + (double)w.Cout * osz);
@@ -497,7 +560,8 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         if (p.s2) bytes += px * w.Cout * esz;
         rec = ctx->prof_open(nm, 2.0 * px * w.KS * w.KS * w.Cin * w.Cout, bytes, st);
     }
-    const int rc = w.rows ? conv_rows_launch(ctx, w, p, st) : w.pw ? conv_pw_launch(ctx, w, p, st)
+    const int rc = w.few ? (w.KS == 3 ? launch_fewcout<3>(ctx, p, st) : launch_fewcout<5>(ctx, p, st))
+                   : w.rows ? conv_rows_launch(ctx, w, p, st) : w.pw ? conv_pw_launch(ctx, w, p, st)
                           : ((w.dtype == SR_DTYPE_BF16) ? dispatch<bf16_t>(ctx, w, p, nct, st) : dispatch<float>(ctx, w, p, nct, st));
     ctx->prof_close(rec, st);
     return rc;
