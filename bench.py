@@ -54,6 +54,27 @@ def cpu_baseline(weights, lr_tile, budget_s=20.0):
                       f"{dt:.1f} s, extrapolated to a 441-patch tile"}
 
 
+def roofline_object(dom, traffic, instrumented_ms_per_step):
+    """The `roofline` object of the bench line for the dominant kernel's profile record `dom` = {kernel, launches, total_ms, flops,
+    bytes} (sums over its launches; flops / bytes are ALGORITHMIC).  Which roof bounds the kernel is decided by the arithmetic
+    intensity of that work against the ridge of the two peaks (MI355X_MICROARCH.md: bf16 MFMA ~2.5 PFLOP/s dense, HBM3E ~8 TB/s
+    -> 312 FLOP/B).  The dense-block convs with 32 output channels sit at 192..247 FLOP/B: below the ridge, so the HBM roof is the
+    one that bounds them; the MFMA view of the same launches is kept beside it."""
+    secs = dom["total_ms"] * 1e-3
+    tflops = dom["flops"] / secs / 1e12
+    gbps = dom["bytes"] / secs / 1e9
+    ai = dom["flops"] / dom["bytes"]
+    ridge = PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBPS
+    common = {"kernel": dom["kernel"], "traffic": traffic, "avg_launch_ms": dom["total_ms"] / dom["launches"], "launches": dom["launches"],
+              "flop_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+              "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+              "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_BF16_TFLOPS, "hbm_gbps": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS,
+              "instrumented_ms_per_step": instrumented_ms_per_step}
+    if ai < ridge:
+        return {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common}
+    return {"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS, **common}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,27 +216,11 @@ def main():
         if prof:
             prof.sort(key=lambda r: -r["total_ms"])
             dom = prof[0]
-            avg_ms = dom["total_ms"] / dom["launches"]
-            ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             traffic = None
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
             if os.path.isfile(tp):
                 traffic = json.load(open(tp)).get(dom["kernel"])
-            # Which roof bounds the kernel: arithmetic intensity of its ALGORITHMIC work against the ridge of the two peaks
-            # (MI355X_MICROARCH.md: bf16 MFMA ~2.5 PFLOP/s dense, HBM3E ~8 TB/s -> 312 FLOP/B).  The dense-block convs with 32
-            # output channels sit at 192..247 FLOP/B: below the ridge, so the HBM roof is the one that bounds them.
-            ai = dom["flops"] / dom["bytes"]
-            tflops = ach
-            gbps = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
-            common = {"kernel": dom["kernel"], "traffic": traffic, "avg_launch_ms": avg_ms, "launches": dom["launches"],
-                      "flop_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
-                      "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBPS,
-                      "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_BF16_TFLOPS, "hbm_gbps": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS,
-                      "instrumented_ms_per_step": elapsed_prof / args.steps * 1e3}
-            if ai < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBPS:
-                roof = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common}
-            else:
-                roof = {"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS, **common}
+            roof = roofline_object(dom, traffic, elapsed_prof / args.steps * 1e3)
         line = {
             "metric": "4x-SR MPix/s on 512x512 LR batch", "value": mpix * args.steps / elapsed, "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
