@@ -319,7 +319,51 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
         }
     };
 
-    for (int k0 = 0; k0 < N; k0 += KT2) {
+    // Fast tile: a full tile whose scores stay within 2^GROW_OK of the running max needs no rescale at all -- the probabilities are
+    // then simply taken relative to the (stale) running max, which is exact: numerator and denominator carry the same power of two.
+    // It returns false, before touching any state, when some score exceeds that bound; the caller then redoes the tile with the
+    // full logic above.  The point is what the fast loop does NOT contain: with the rescale branch inside the key loop, hipcc
+    // joins the branch's new accumulators / denominators / query fragments with the untouched ones in a phi and copies all 48
+    // registers on the common path of every tile (24 v_mov_b64), and the loop also pays the vote; a loop made of fast tiles only
+    // has neither (attention 241 -> ~185 ms per two bench steps).
+    constexpr float GROW_OK = 40.f;    // 2^40 x 9216 keys x |v|: far inside fp32 for the sums and the bf16 probabilities
+    auto tile_fast = [&](const bf16x8 kf, const int sub) -> bool {
+        f32x16 s[QB];
+        bool risky = false;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb[j], zero16, 0, 0, 0);
+            float m = fmaxf(fmaxf(s[j][0], s[j][1]), s[j][2]);
+#pragma unroll
+            for (int i = 3; i + 1 < 16; i += 2) m = fmaxf(fmaxf(m, s[j][i]), s[j][i + 1]);
+            m = fmaxf(m, s[j][15]);
+            risky = risky || m > GROW_OK;
+        }
+        if (__any(risky)) return false;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[j][i] = __builtin_amdgcn_exp2f(s[j][i]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char* vrow = vt + r * PITCH2 + (sub * 32 + 16 * ks + 4 * h) * 2;
+            const bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow);
+            const bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + 16);
+            const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[j][8 * ks + e];
+                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[j], 0, 0, 0);
+                lacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, pf, lacc[j], 0, 0, 0);
+            }
+        }
+        return true;
+    };
+    // V^T of KT2 keys into LDS, two keys per dword (every wave of the workgroup passes here once per key group, in either mode)
+    auto stage_v = [&](const int k0) {
         __syncthreads();
 #pragma unroll
         for (int part = 0; part < KT2 / 128; ++part) {
@@ -335,15 +379,36 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < KT2 / 32; ++sub) {
+    };
+    // the tiles [sub0, KT2/32) of key group k0 with the full logic
+    auto slow_tiles = [&](const int k0, const int sub0, bf16x8 kf) {
+        for (int sub = sub0; sub < KT2 / 32; ++sub) {
             const int kb = k0 + sub * 32;
             if (kb >= N) break;
-            const bf16x8 kf = knext;
-            knext = load_k(kb + 32);                       // next tile's keys fly under this tile's softmax
+            if (sub != sub0) { kf = knext; knext = load_k(kb + 32); }
             if (kb + 32 <= N) tile(kf, sub, kb, false_c, kb == 0);  // full tile: no masking code at all
             else tile(kf, sub, kb, true_c, kb == 0);                // ragged last tile: keys >= N get -inf
         }
+    };
+
+    // Key groups: fast tiles while they last, the full logic for the rest of the group (the first group, which sets the running max,
+    // the ragged tail, and any group in which a score outgrew the bound).  The conditional slow part sits once per GROUP, so the
+    // copies its phi costs are paid once per four tiles instead of in every tile.
+    for (int k0 = 0; k0 < N; k0 += KT2) {
+        stage_v(k0);
+        int sub = 0;
+        bf16x8 kf = knext;
+        if (k0 != 0 && k0 + KT2 <= N) {
+#pragma unroll
+            for (; sub < KT2 / 32; ++sub) {
+                kf = knext;
+                knext = load_k(k0 + sub * 32 + 32);          // next tile's keys fly under this tile's softmax
+                if (!tile_fast(kf, sub)) break;
+            }
+        } else {
+            knext = load_k(k0 + 32);
+        }
+        if (sub < KT2 / 32) slow_tiles(k0, sub, kf);
     }
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
