@@ -4,8 +4,10 @@
 One step = one pass of the hot path over one batch: 16 LR tiles [512,512,3] (resident in HBM) ->
 ESRGAN.super_resolve_image (reference patch mode: reflect pad, 441 LR patches 48x48 stride 24 per tile,
 RRDB generator x4 NB=23 G=32 with both SelfAttention layers, bf16 storage / fp32 accumulate, overlap
-average, crop, clip) -> PSNR/SSIM against the HR tiles -> (N>1) all-reduce of the metric sums over RCCL.
-Weak scaling: every rank owns 16 tiles.  value = SR output megapixels of all ranks / wall time (max over ranks).
+average, crop, clip) -> PSNR/SSIM against the HR tiles -> (N>1) all-reduce of the metric sums over RCCL (sr355/dist.py).
+N>1 default = SURVEY.md 8(e)'s partition: the 16-tile batch is split B/g over the ranks ("scaling": "strong": 16/8/4/2 tiles per
+GPU at 1/2/4/8); --scaling weak gives every rank its own 16 tiles.  value = SR output megapixels of all ranks / wall time
+(max over ranks).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -31,18 +33,29 @@ PEAK_HBM_GBPS = 8000.0        # HBM3E, MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
-def cpu_baseline(weights, lr_tile, budget_s=20.0):
-    """The oracle (CPU restatement, torch-CPU fp32, all host cores) on a bounded sample of the same patches."""
-    from oracle import models as OM
+CONV_TFLOP_PER_TILE = 36.48  # conv FLOP one 512x512 LR tile needs in reference patch mode (441 patches 48x48)
+N_PARITY = 2                 # LR patches of tile 0 pushed through both the GPU and the oracle for the parity object
+
+
+def tile_patches(lr_tile):
     from oracle import ops as OO
-    threads = min(os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU
-    torch.set_num_threads(threads)
     padded = OO.add_padding(lr_tile, PATCH, STRIDE)
     patches, _ = OO.extract_patches(padded, PATCH, STRIDE)
-    x = patches * 2.0 - 1.0
+    return patches * 2.0 - 1.0
+
+
+def cpu_baseline(weights, lr_tile, budget_s=20.0, keep=None):
+    """The oracle (CPU restatement, torch-CPU fp32, all host cores) on a bounded sample of the same patches.  `keep`, a dict,
+    receives the oracle's output for the first N_PARITY patches (the parity object compares the GPU with them)."""
+    from oracle import models as OM
+    threads = min(os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU
+    torch.set_num_threads(threads)
+    x = tile_patches(lr_tile)
     t0 = time.perf_counter()
-    OM.esrgan_g_forward(x[:2], weights, SCALE, NB)
+    first = OM.esrgan_g_forward(x[:2], weights, SCALE, NB)
     per_patch = (time.perf_counter() - t0) / 2
+    if keep is not None:
+        keep["fp32_reference_graph"] = first[:N_PARITY]
     n = int(min(len(x) - 2, max(2, budget_s / max(per_patch, 1e-3))))
     t0 = time.perf_counter()
     for i in range(2, 2 + n, 2):
@@ -54,12 +67,32 @@ def cpu_baseline(weights, lr_tile, budget_s=20.0):
                       f"{dt:.1f} s, extrapolated to a 441-patch tile"}
 
 
-def roofline_object(dom, traffic, instrumented_ms_per_step):
+def parity_object(ctx, model, weights, lr_tile, fp32_ref):
+    """GPU (the bench's bf16 generator) vs the oracle on the first N_PARITY LR patches of tile 0, outside the timed region.
+    Like-for-like = the oracle in its bf16-storage mode (rounds to bf16 where the device stores bf16); the plain fp32 reference
+    graph is reported beside it."""
+    from oracle import models as OM
+    from oracle import ops as OO
+    from sr355.weights import round_to_bf16
+    x = round_to_bf16(tile_patches(lr_tile)[:N_PARITY].astype(np.float32))
+    got = model.generator.forward(ctx.to_device(x, torch.bfloat16)).float().cpu().numpy()
+    ref = OM.esrgan_g_forward(x, weights, SCALE, NB, bf16_storage=True)
+    p01 = lambda a, b: float(OO.psnr((a + 1) / 2, (b + 1) / 2, dtype=np.float64).min())
+    out = {"psnr_gpu_vs_oracle_db": p01(got, ref), "max_abs": float(np.abs(got - ref).max()),
+           "rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "n_patches": int(len(x)),
+           "oracle": "CPU restatement, fp32 arithmetic, bf16 storage where the device stores bf16 (oracle.models bf16_storage=True)"}
+    if fp32_ref is not None:
+        out["psnr_gpu_vs_fp32_reference_graph_db"] = p01(got, fp32_ref[:len(x)])
+    return out
+
+
+def roofline_object(dom, traffic, instrumented_ms_per_step, clock_mhz=None):
     """The `roofline` object of the bench line for the dominant kernel's profile record `dom` = {kernel, launches, total_ms, flops,
-    bytes} (sums over its launches; flops / bytes are ALGORITHMIC).  Which roof bounds the kernel is decided by the arithmetic
-    intensity of that work against the ridge of the two peaks (MI355X_MICROARCH.md: bf16 MFMA ~2.5 PFLOP/s dense, HBM3E ~8 TB/s
-    -> 312 FLOP/B).  The dense-block convs with 32 output channels sit at 192..247 FLOP/B: below the ridge, so the HBM roof is the
-    one that bounds them; the MFMA view of the same launches is kept beside it."""
+    bytes} (sums over its launches; flops / bytes are ALGORITHMIC).  SURVEY.md 8(d) and the north star define this path's roof as
+    CONV ARITHMETIC: achieved = algorithmic conv FLOP / launch time against the dense bf16 MFMA peak (MI355X_MICROARCH.md:
+    ~2.5 PFLOP/s).  The HBM view of the same launches (algorithmic bytes / time against 8 TB/s), the arithmetic intensity and which
+    of the two roofs is the tighter one for this kernel are kept beside it; `peak_at_measured_clock` re-prices the MFMA peak at the
+    shader clock measured under MFMA load in this run (256 CUs x 4096 FLOP/clk)."""
     secs = dom["total_ms"] * 1e-3
     tflops = dom["flops"] / secs / 1e12
     gbps = dom["bytes"] / secs / 1e9
@@ -70,8 +103,10 @@ def roofline_object(dom, traffic, instrumented_ms_per_step):
               "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
               "mfma_tflops": tflops, "mfma_frac": tflops / PEAK_BF16_TFLOPS, "hbm_gbps": gbps, "hbm_frac": gbps / PEAK_HBM_GBPS,
               "instrumented_ms_per_step": instrumented_ms_per_step}
-    if ai < ridge:
-        return {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common}
+    common["tighter_roof"] = "hbm" if ai < ridge else "mfma"
+    if clock_mhz:
+        pk = 256 * 4096 * clock_mhz * 1e6 / 1e12
+        common.update({"clock_mhz_under_mfma_load": clock_mhz, "peak_at_measured_clock": pk, "frac_at_measured_clock": tflops / pk})
     return {"bound": "mfma", "achieved": tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS, **common}
 
 
@@ -87,39 +122,33 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel pass (no roofline object)")
     ap.add_argument("--no-attention", action="store_true", help="non-reference graph, kernel tuning only")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
+                    help="N>1: strong (default) = the 16-tile batch split over the ranks (SURVEY.md 8e); weak = 16 tiles per rank")
+    ap.add_argument("--tiles", type=int, default=TILES_PER_GPU, help="tiles this rank processes at N=1 (profiles/: 2/4/8/16 = what a rank sees at N=8/4/2/1)")
+    ap.add_argument("--raw-glorot", action="store_true",
+                    help="round 1's weights: glorot without conditioning the attention logits (sr355.weights.condition_attention)")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
     if args.chunk <= 0:
         args.chunk = 441 * max(1, args.tiles_per_call)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    from sr355 import dist as D
     if os.environ.get("SR355_ONE_DEVICE"):                     # rehearsal of the N>1 plumbing on a 1-GPU box: every rank drives cuda:0
+        torch.cuda.set_device(0)
+    else:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local = D.init_from_env(backend=os.environ.get("SR355_DIST_BACKEND", "nccl"))   # "gloo" only for that rehearsal
+    if os.environ.get("SR355_ONE_DEVICE"):
         local = 0
-    torch.cuda.set_device(local)
-    import torch.distributed as dist
-    backend = os.environ.get("SR355_DIST_BACKEND", "nccl")     # "gloo" only for that rehearsal
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
-        dist.init_process_group(backend, **kw)
-
-    def allreduce(t, op=dist.ReduceOp.SUM):
-        if world == 1:
-            return t
-        if backend == "nccl":
-            dist.all_reduce(t, op=op)
-            return t
-        c = t.cpu()
-        dist.all_reduce(c, op=op)
-        t.copy_(c)
-        return t
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    my_tiles, global_tiles = D.partition_tiles(args.tiles, rank, world, scaling)
+    n_mine = len(my_tiles)
 
     from sr355 import Context
     from sr355.synth import make_pairs
-    from sr355.weights import init_weights
+    from sr355.weights import bf16_rounded, condition_attention, init_weights
     from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
 
     ctx = Context.get(local)
@@ -129,22 +158,26 @@ def main():
         m_.setup_model(scale_factor=SCALE, growth_channels=G, num_rrdb_blocks=NB, use_attention=not args.no_attention)
         if not models:
             weights = init_weights(m_.generator.layer_shapes(), seed=3000)
+            if not args.raw_glorot:
+                weights = condition_attention(weights)
+            weights = bf16_rounded(weights)      # what the device holds anyway; the oracle then sees bit-identical parameters
         m_.set_weights(weights)
         models.append(m_)
     model = models[0]
     streams = [torch.cuda.Stream(device=ctx.torch_device) for _ in models] if len(models) > 1 else [None]
 
-    # synthetic 3D-print tiles, seeded per rank; 4 distinct tiles repeated to 16
-    lr4, hr4 = make_pairs(4, LR, LR, SCALE, seed=42 + 2 + 1000 * rank)
-    reps = TILES_PER_GPU // 4
-    lr = ctx.to_device(np.tile(lr4, (reps, 1, 1, 1)))
-    hr = ctx.to_device(np.tile(hr4, (reps, 1, 1, 1)))
+    # synthetic 3D-print tiles: 4 distinct tiles per global batch of 16, tile t of the batch = distinct tile t % 4;
+    # a rank holds only its own shard of the batch in HBM
+    seed = 42 + 2 + (1000 * rank if scaling == "weak" else 0)
+    lr4, hr4 = make_pairs(4, LR, LR, SCALE, seed=seed)
+    lr = ctx.to_device(np.stack([lr4[t % 4] for t in my_tiles])) if n_mine else None
+    hr = ctx.to_device(np.stack([hr4[t % 4] for t in my_tiles])) if n_mine else None
     sums = torch.zeros(3, dtype=torch.float64, device=ctx.torch_device)
 
     def step():
         sums.zero_()
         g = max(1, args.tiles_per_call)
-        groups = [list(range(t0, min(t0 + g, TILES_PER_GPU))) for t0 in range(0, TILES_PER_GPU, g)]
+        groups = [list(range(t0, min(t0 + g, n_mine))) for t0 in range(0, n_mine, g)]
         done = []
         cur = torch.cuda.current_stream(ctx.torch_device)
         for gi, ts in enumerate(groups):
@@ -165,12 +198,11 @@ def main():
                 sums[0] += ctx.psnr(hr[t:t + 1], sr[None])[0].double()
                 sums[1] += ctx.ssim(hr[t:t + 1], sr[None])[0].double()
                 sums[2] += 1.0
-        allreduce(sums)                    # RCCL over xGMI: the path's only exchange step
+        D.allreduce_metric_sums(sums)      # RCCL over xGMI: the path's only exchange step
         return sums
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     # One un-timed sizing pass: the generator's workspaces are allocated on first use (~115 GB at 16 tiles per call).  Should that
@@ -206,12 +238,13 @@ def main():
         elapsed_prof = time.perf_counter() - t1
         prof = ctx.profile_end()
     et = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
-    allreduce(et, dist.ReduceOp.MAX)
+    D.allreduce_max(et)
     elapsed = float(et.item())
     res = out.cpu().numpy()
 
     if rank == 0:
-        mpix = world * TILES_PER_GPU * (LR * SCALE) ** 2 / 1e6
+        mpix = global_tiles * (LR * SCALE) ** 2 / 1e6
+        clock_mhz = None if args.no_profile else ctx.measure_clock_mhz()
         roof = None
         if prof:
             prof.sort(key=lambda r: -r["total_ms"])
@@ -220,28 +253,35 @@ def main():
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
             if os.path.isfile(tp):
                 traffic = json.load(open(tp)).get(dom["kernel"])
-            roof = roofline_object(dom, traffic, elapsed_prof / args.steps * 1e3)
+            roof = roofline_object(dom, traffic, elapsed_prof / args.steps * 1e3, clock_mhz)
         line = {
             "metric": "4x-SR MPix/s on 512x512 LR batch", "value": mpix * args.steps / elapsed, "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: ESRGAN-RRDB x4 (NB=23,G=32,2xSelfAttention) on 16 LR tiles 512x512 per GPU, "
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (seeded 3D-print tiles; seeded glorot-uniform weights" + ("" if args.raw_glorot else
+                    ", attention logits conditioned by 2^-8: sr355.weights.condition_attention") + ")",
+            "config": {"workload": f"BASELINE configs[2]: ESRGAN-RRDB x4 (NB=23,G=32,2xSelfAttention) on a batch of {global_tiles} LR tiles 512x512, "
                                    "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
-                       "tiles_per_gpu": TILES_PER_GPU, "global_batch": world * TILES_PER_GPU, "patches_per_forward": args.chunk,
+                       "tiles_this_rank": n_mine, "global_batch": global_tiles, "patches_per_forward": min(args.chunk, 441 * max(n_mine, 1)),
                        "tiles_per_call": args.tiles_per_call,
                        "parallelism": f"dp{world} (tile shards, metric all-reduce only)"},
             "quality": {"mean_psnr_vs_hr_db": res[0] / res[2], "mean_ssim_vs_hr": res[1] / res[2], "note": "random-init weights"},
+            "whole_step": {"conv_tflop": CONV_TFLOP_PER_TILE * global_tiles, "conv_tflops_all_ranks": CONV_TFLOP_PER_TILE * global_tiles / (elapsed / args.steps),
+                           "frac_of_bf16_mfma_peak": CONV_TFLOP_PER_TILE * global_tiles / (elapsed / args.steps) / (PEAK_BF16_TFLOPS * world),
+                           "note": "SURVEY.md 8(d): conv FLOP the patch-mode batch needs / wall time of the whole step (attention, plumbing and metrics included in the time)"},
             "roofline": roof,
             "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
                          "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2),
                          "gbps": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in prof[:8]],
         }
+        kept = {}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(weights, lr4[0])
+            line["cpu_baseline"] = cpu_baseline(weights, lr4[0], keep=kept)
+        if world == 1 and not args.no_parity and not args.no_attention:
+            line["parity"] = parity_object(ctx, model, weights, lr4[0], kept.get("fp32_reference_graph"))
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        D.shutdown()
 
 
 if __name__ == "__main__":

@@ -68,6 +68,11 @@ int  sr_mem_info(sr_ctx* ctx, int64_t* current_bytes, int64_t* peak_bytes);
  * blocks until that forward has finished. */
 int  sr_last_forward_ms(sr_ctx* ctx, float* ms);
 
+/* Shader clock (MHz) the GPU holds under a dense bf16 MFMA load, measured in-kernel (s_memtime / s_memrealtime around an
+ * MFMA loop, ~0.3 s of load first).  bench.py prices the MFMA roof at this clock beside the nominal peak -- the reference
+ * has no counterpart (it never names its hardware).  Blocks until measured. */
+int  sr_measure_clock(sr_ctx* ctx, float* mhz, void* stream);
+
 /* Per-launch timing of the hot kernels with HIP events recorded on the launching stream (the
  * reference's analogue is its time.perf_counter() bracket around predict, SRCNN_model.py:208-212).
  * begin: start collecting; end: synchronise the device and write a JSON array
@@ -76,6 +81,9 @@ int  sr_last_forward_ms(sr_ctx* ctx, float* ms);
 /* Diagnostic only (never set in production): a device buffer of 16 uint64 per workgroup of the next 3x3 bf16 conv
  * launches; a separately compiled stamped variant of the kernel writes s_memtime stamps there (NULL switches back). */
 int  sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer);
+/* Test hook: device allocations through this ctx fail (SR_ERR_OOM) once the bytes it holds would exceed `bytes`
+ * (0 = no cap).  Lets the tests walk the out-of-memory path of sr_forward without filling a 288 GB card. */
+int  sr_debug_set_alloc_cap(sr_ctx* ctx, int64_t bytes);
 int  sr_profile_begin(sr_ctx* ctx);
 int  sr_profile_end(sr_ctx* ctx, char* json, int64_t cap);
 
@@ -94,6 +102,17 @@ int  sr_model_set_weight(sr_model* m, const char* keras_layer_name, int which,
                          const float* host, const int64_t* shape, int ndim);
 /* pack all weights into the device MFMA layouts; must precede sr_forward. */
 int  sr_model_finalize(sr_model* m);
+/* Free the model's activation workspaces (they are grow-only otherwise; weights stay).  sr_forward releases them by
+ * itself when growing them fails with SR_ERR_OOM, so a retry with a smaller batch starts clean -- the analogue of
+ * the reference's tf.keras.backend.clear_session() between runs (defect_detection_pipeline / notebooks). */
+int  sr_model_release_workspace(sr_model* m);
+/* Diagnostics for stage-by-stage parity traces (tests/): the graph as a flat op list -- name = Keras layer name of a
+ * conv (ESRGAN_model.py:230-341), else the op kind; the op's output is [B, (H*mul)>>shift, (W*mul)>>shift, channels]
+ * (channels 0: no tensor output) -- and a tap that copies op `op_index`'s output, as dense fp32 NHWC, into
+ * `device_dst` during every later sr_forward (NULL removes the tap).  Never set in production runs. */
+int  sr_model_num_ops(sr_model* m);
+int  sr_model_op_info(sr_model* m, int index, const char** name, int* channels, int* mul, int* shift);
+int  sr_model_set_tap(sr_model* m, int op_index, float* device_dst, int64_t capacity);
 /* output shape for an input of [B,H,W,C]. */
 int  sr_model_output_shape(sr_model* m, int B, int H, int W, int C, int64_t out_shape[4]);
 /* model.predict / generator(x): SRCNN_model.py:210, EDSR_model.py:274, ESRGAN_model.py:941,

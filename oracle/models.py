@@ -120,45 +120,78 @@ def edsr_forward(x, w, scale=2, num_res_blocks=16, res_scaling=0.1, dtype=np.flo
     return np.clip(x, 0.0, 1.0)
 
 
-def _dense_block(x, w, name, dtype):
-    """ESRGAN_model.py:212-254."""
+def _id(x):
+    return x
+
+
+def _dense_block(x, w, name, dtype, q=_id):
+    """ESRGAN_model.py:212-254.  q = storage rounding of the four growth convs (identity in the reference's fp32); the
+    block's own output x + 0.2*conv5 is returned UNROUNDED: the caller rounds it where the device stores it."""
     feats = [x]
     for k in range(1, 5):
-        feats.append(ops.conv2d(np.concatenate(feats, axis=-1), *w[f"{name}_conv{k}"], act="relu", dtype=dtype))
+        feats.append(q(ops.conv2d(np.concatenate(feats, axis=-1), *w[f"{name}_conv{k}"], act="relu", dtype=dtype)))
     x5 = ops.conv2d(np.concatenate(feats, axis=-1), *w[f"{name}_conv5"], dtype=dtype)
     return x + x5 * dtype(0.2)
 
 
-def _sa(x, w, name, dtype, parts=None):
-    r = ops.self_attention(x, *w[f"{name}_f"], *w[f"{name}_g"], *w[f"{name}_h"], *w[f"{name}_v"], dtype=dtype,
+def _sa(x, w, name, dtype, parts=None, bf16_storage=False):
+    fn = ops.self_attention_bf16_storage if bf16_storage else ops.self_attention
+    r = fn(x, *w[f"{name}_f"], *w[f"{name}_g"], *w[f"{name}_h"], *w[f"{name}_v"], dtype=dtype,
                            return_parts=parts is not None)
     if parts is not None:
-        parts[name] = r[1]
+        parts[name + "/parts"] = r[1]
         return r[0]
     return r
 
 
-def esrgan_g_forward(x, w, scale=2, num_rrdb=23, dtype=np.float32, attention=True, parts=None):
-    """ESRGAN_model.py:303-345.  x in [-1,1]; output tanh in [-1,1]."""
-    x = ops.conv2d(x, *w["initial_conv"], dtype=dtype)
+def esrgan_g_forward(x, w, scale=2, num_rrdb=23, dtype=np.float32, attention=True, parts=None, bf16_storage=False,
+                     bf16_output=True):
+    """ESRGAN_model.py:303-345.  x in [-1,1]; output tanh in [-1,1].
+
+    bf16_storage=True is the same graph with every tensor the bf16 device path keeps in HBM rounded to bf16 where the
+    device rounds it (csrc/api.hip build_esrgan): one rounding per fused conv epilogue -- so x + 0.2*conv5 once, and
+    rrdb_in + 0.2*(x + 0.2*conv5) once for the third dense block of an RRDB, whose own output is never stored -- plus the
+    attention roundings of ops.self_attention_bf16_storage.  Arithmetic inside a layer stays in `dtype`.  It is the
+    like-for-like reference for BASELINE configs[2] (bf16): what is left between it and the device is accumulation
+    order.  `parts`, when a dict, also receives the stage outputs 'initial_conv', 'rrdb_<b>', 'trunk_add',
+    'upsample_<i>', 'final_conv1' (the trace the parity tests compare stage by stage)."""
+    q = ops.round_bf16 if bf16_storage else _id
+    if bf16_storage:
+        x = q(np.asarray(x, dtype=dtype))
+    x = q(ops.conv2d(x, *w["initial_conv"], dtype=dtype))
     trunk = x
+    if parts is not None:
+        parts["initial_conv"] = x
     for b in range(num_rrdb):
         r_in = x
         for d in (1, 2, 3):
-            x = _dense_block(x, w, f"rrdb_{b}_dense{d}", dtype)
-        x = r_in + x * dtype(0.2)
-    x = trunk + ops.conv2d(x, *w["trunk_conv"], dtype=dtype)
+            x = _dense_block(x, w, f"rrdb_{b}_dense{d}", dtype, q)
+            if d < 3:
+                x = q(x)
+        x = q(r_in + x * dtype(0.2))
+        if parts is not None:
+            parts[f"rrdb_{b}"] = x
+    x = q(trunk + ops.conv2d(x, *w["trunk_conv"], dtype=dtype))
     if parts is not None:
         parts["trunk_add"] = x
     if attention:
-        x = _sa(x, w, "self_attention_trunk", dtype, parts)
+        x = _sa(x, w, "self_attention_trunk", dtype, parts, bf16_storage)
+        if parts is not None:
+            parts["self_attention_trunk"] = x
     for i in range(int(np.log2(scale))):
-        x = ops.conv2d(x, *w[f"upsample_{i}_conv"], dtype=dtype)
-        x = ops.activation(ops.depth_to_space(x, 2), "lrelu")
+        x = q(ops.activation(ops.conv2d(x, *w[f"upsample_{i}_conv"], dtype=dtype), "lrelu"))
+        x = ops.depth_to_space(x, 2)
+        if parts is not None:
+            parts[f"upsample_{i}"] = x
         if i == 0 and attention:
-            x = _sa(x, w, "self_attention_upsample_0", dtype, parts)
-    x = ops.conv2d(x, *w["final_conv1"], act="relu", dtype=dtype)
-    return ops.conv2d(x, *w["final_conv2"], act="tanh", dtype=dtype)
+            x = _sa(x, w, "self_attention_upsample_0", dtype, parts, bf16_storage)
+            if parts is not None:
+                parts["self_attention_upsample_0"] = x
+    x = q(ops.conv2d(x, *w["final_conv1"], act="relu", dtype=dtype))
+    if parts is not None:
+        parts["final_conv1"] = x
+    y = ops.conv2d(x, *w["final_conv2"], act="tanh", dtype=dtype)
+    return q(y) if bf16_output else y
 
 
 def vgg16_features(x, w, cfg=VGG16_CFG, dtype=np.float32):

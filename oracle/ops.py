@@ -16,6 +16,20 @@ def _t(x, dtype):
 
 
 # --------------------------------------------------------------------------------------
+# bf16 storage model (not a reference semantic: BASELINE configs[2] asks for bf16 on the device, and
+# the device keeps activations in bf16 BETWEEN layers while every layer accumulates in fp32)
+# --------------------------------------------------------------------------------------
+def round_bf16(x):
+    """Round to the nearest bf16 (ties to even) and return it in x's dtype: what a bf16 store followed by a load does.
+    The graphs in oracle/models.py take this as `store=` and apply it exactly where the device writes bf16 (after each
+    fused conv epilogue, the attention projections, the probabilities and the attention output)."""
+    x = np.asarray(x)
+    out_dtype = x.dtype if x.dtype in (np.float32, np.float64) else np.float32
+    a = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    return a.to(torch.bfloat16).to(torch.float32).numpy().astype(out_dtype, copy=False)
+
+
+# --------------------------------------------------------------------------------------
 # Activations (Keras semantics; SURVEY.md A.12)
 # --------------------------------------------------------------------------------------
 def activation(x, act):
@@ -138,6 +152,31 @@ def self_attention(x, wf, bf, wg, bg, wh, bh, wv, bv, dtype=np.float32, return_p
     o = np.matmul(s, h).reshape(B, H, W, -1).astype(dtype)
     ov = conv2d(o, wv, bv, dtype=dtype)
     y = x + ov
+    if return_parts:
+        return y, dict(f=f, g=g, h=h, o=o)
+    return y
+
+
+def self_attention_bf16_storage(x, wf, bf, wg, bg, wh, bh, wv, bv, dtype=np.float32, return_parts=False):
+    """SelfAttention (ESRGAN_model.py:48-70) as the bf16 device path stores it -- same function as self_attention() up to
+    rounding, restated with a rounding at every point where csrc/attention.hip and the projections keep bf16:
+    the key projection f is packed pre-multiplied by log2(e) (so the softmax runs as 2^(s - max)) and rounded to bf16 again,
+    f/g/h are stored in bf16, the probabilities are rounded to bf16 before they are summed (denominator) and multiplied with
+    h (numerator), the normalised output is stored in bf16, and x + v(o) is stored in bf16."""
+    q = round_bf16
+    x = np.asarray(x, dtype=dtype)
+    B, H, W, C = x.shape
+    log2e = np.float32(1.4426950408889634)
+    wf2 = q(np.asarray(wf, np.float32) * log2e)
+    bf2 = None if bf is None else np.asarray(bf, np.float32) * log2e
+    f = q(conv2d(x, wf2, bf2, dtype=dtype)).reshape(B, H * W, -1)
+    g = q(conv2d(x, wg, bg, dtype=dtype)).reshape(B, H * W, -1)
+    h = q(conv2d(x, wh, bh, dtype=dtype)).reshape(B, H * W, -1)
+    s = np.matmul(g, f.transpose(0, 2, 1))
+    s -= s.max(axis=-1, keepdims=True)
+    p = q(np.exp2(s))
+    o = q(np.matmul(p, h) / p.sum(axis=-1, keepdims=True)).reshape(B, H, W, -1).astype(dtype)
+    y = q(x + conv2d(o, wv, bv, dtype=dtype))
     if return_parts:
         return y, dict(f=f, g=g, h=h, o=o)
     return y

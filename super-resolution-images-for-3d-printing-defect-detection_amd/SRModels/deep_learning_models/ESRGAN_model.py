@@ -79,8 +79,9 @@ class ESRGAN(DeviceModelMixin):
 
     def super_resolve_image(self, lr_img, patch_size_lr=48, stride=24, batch_size=16):
         """Reflect-pad, cut LR patches, [0,1]->[-1,1], generator, (out+1)/2, overlap-average, crop, clip
-        (ESRGAN_model.py:858-979).  `batch_size` is Keras' predict chunk; chunking does not change results, so the
-        device chunk is max(batch_size, 147) patches."""
+        (ESRGAN_model.py:858-979).  `batch_size` is Keras' predict chunk (:941) and is honoured as given -- `time_sec` times
+        exactly the chunking the caller asked for.  Chunking never changes results; for throughput pass a large batch_size
+        (bench.py hands over all patches of its tiles at once)."""
         if not self.trained:
             raise RuntimeError("Model has not been trained or loaded.")
         if self.generator is None:
@@ -88,7 +89,7 @@ class ESRGAN(DeviceModelMixin):
         if not hasattr(self, "scale_factor") or self.scale_factor is None:
             raise ValueError("scale_factor is not set. Ensure setup_model was called.")
         lr, is_np = P.as_device_image(self.ctx, lr_img)
-        sr, metrics = P.patchwise_sr(self.generator, lr, patch_size_lr, stride, self.scale_factor, chunk=max(int(batch_size), 147),
+        sr, metrics = P.patchwise_sr(self.generator, lr, patch_size_lr, stride, self.scale_factor, chunk=max(int(batch_size), 1),
                                      in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5)
         return (sr.cpu().numpy() if is_np else sr), metrics
 
@@ -99,7 +100,7 @@ class ESRGAN(DeviceModelMixin):
             raise RuntimeError("Model has not been trained or loaded.")
         conv = [P.as_device_image(self.ctx, im) for im in lr_imgs]
         srs, metrics = P.patchwise_sr_many(self.generator, [c[0] for c in conv], patch_size_lr, stride, self.scale_factor,
-                                           chunk=max(int(batch_size), 147), in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5, timed=timed)
+                                           chunk=max(int(batch_size), 1), in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5, timed=timed)
         return [sr.cpu().numpy() if c[1] else sr for sr, c in zip(srs, conv)], metrics
 
     def save(self, directory, timestamp):

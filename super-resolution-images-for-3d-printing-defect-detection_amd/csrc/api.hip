@@ -23,6 +23,10 @@
 void* sr_ctx::dalloc(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0) bytes = 16;
+    if (alloc_cap > 0 && cur_bytes + (int64_t)bytes > alloc_cap) {
+        err = "allocation of " + std::to_string(bytes) + " bytes exceeds the debug cap (sr_debug_set_alloc_cap)";
+        return nullptr;
+    }
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
@@ -38,6 +42,13 @@ void sr_ctx::dfree(void* p) {
     auto it = allocs.find(p);
     if (it != allocs.end()) { cur_bytes -= (int64_t)it->second; allocs.erase(it); }
     (void)hipFree(p);
+}
+int sr_ctx::ensure_dyn_lds(const void* kernel, int bytes) {
+    if (lds_attr_done.count(kernel)) return SR_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(SR_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    lds_attr_done.insert(kernel);
+    return SR_OK;
 }
 void* sr_ctx::scratch(size_t bytes) {
     if (bytes <= scratch_cap) return scratch_buf;
@@ -104,6 +115,9 @@ struct sr_model {
     int in_C = 3, out_C = 3, out_mul = 1; bool out_vec = false;
     bool finalized = false;
     std::vector<size_t> bufcap;       // bytes currently allocated per workspace buffer (grow-only)
+    struct Tap { float* dst; int64_t cap; };
+    std::unordered_map<int, Tap> taps; // diagnostic: op index -> device fp32 destination (sr_model_set_tap)
+    std::vector<std::string> op_names; // per op, for sr_model_op_info
 
     int find_param(const std::string& n, int which) const {
         for (size_t i = 0; i < params.size(); ++i) if (params[i].which == which && params[i].name == n) return (int)i;
@@ -304,7 +318,9 @@ inline void buf_hw(const BufSpec& b, int H, int W, int* h, int* w) { *h = (H * b
 // Workspaces grow on demand and are never shrunk.  Every buffer is [pixels][Cbuf]: the position of the pad
 // channels inside a pixel does not depend on (B,H,W), so zeroing them once at allocation stays valid for every
 // later shape (no kernel ever writes a pad channel).
-int ensure_workspace(sr_model* m, int B, int H, int W) {
+// On an allocation failure every workspace buffer is released (after a device sync: earlier forwards may still be running on
+// them) so that a retry with a smaller batch starts from a clean slate instead of from the half-grown oversized set.
+int ensure_workspace(sr_model* m, int B, int H, int W, hipStream_t st) {
     if (m->bufp.size() != m->bufs.size()) { m->bufp.assign(m->bufs.size(), nullptr); m->bufcap.assign(m->bufs.size(), 0); }
     for (size_t i = 0; i < m->bufs.size(); ++i) {
         const BufSpec& b = m->bufs[i];
@@ -314,8 +330,14 @@ int ensure_workspace(sr_model* m, int B, int H, int W) {
         if (bytes <= m->bufcap[i]) continue;
         if (m->bufp[i]) { SR_HIP(m->ctx, hipDeviceSynchronize()); m->ctx->dfree(m->bufp[i]); m->bufp[i] = nullptr; m->bufcap[i] = 0; }
         m->bufp[i] = m->ctx->dalloc(bytes);
-        if (!m->bufp[i]) return SR_ERR_OOM;
-        SR_HIP(m->ctx, hipMemset(m->bufp[i], 0, bytes));
+        if (!m->bufp[i]) {
+            const std::string why = m->ctx->err;
+            (void)hipDeviceSynchronize();
+            m->free_bufs();
+            return m->ctx->fail(SR_ERR_OOM, "workspace for [" + std::to_string(B) + "," + std::to_string(H) + "," + std::to_string(W) + "]: " + why +
+                                                " (all workspaces of this model were released)");
+        }
+        SR_HIP(m->ctx, hipMemsetAsync(m->bufp[i], 0, bytes, st));   // on the forward's stream: ordered before its first kernel
         m->bufcap[i] = bytes;
     }
     return SR_OK;
@@ -342,6 +364,7 @@ int sr_init(int device_id, sr_ctx** out) {
 }
 
 void sr_destroy(sr_ctx* ctx) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return;
     (void)hipDeviceSynchronize();
     std::vector<void*> ps;
@@ -364,6 +387,7 @@ int sr_mem_info(sr_ctx* ctx, int64_t* current_bytes, int64_t* peak_bytes) {
 }
 
 int sr_last_forward_ms(sr_ctx* ctx, float* ms) {
+    DeviceGuard dg_(ctx);
     if (!ctx || !ms) return SR_ERR_INVALID;
     if (!ctx->timed) return ctx->fail(SR_ERR_STATE, "no forward has run on this ctx");
     SR_HIP(ctx, hipEventSynchronize(ctx->ev1));
@@ -377,6 +401,18 @@ int sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer) {
     return SR_OK;
 }
 
+int sr_measure_clock(sr_ctx* ctx, float* mhz, void* stream) {
+    if (!ctx || !mhz) return SR_ERR_INVALID;
+    DeviceGuard dg_(ctx);
+    return clock_probe_launch(ctx, mhz, static_cast<hipStream_t>(stream));
+}
+
+int sr_debug_set_alloc_cap(sr_ctx* ctx, int64_t bytes) {
+    if (!ctx) return SR_ERR_INVALID;
+    ctx->alloc_cap = bytes > 0 ? bytes : 0;
+    return SR_OK;
+}
+
 int sr_profile_begin(sr_ctx* ctx) {
     if (!ctx) return SR_ERR_INVALID;
     for (auto& r : ctx->prof_recs) { ctx->ev_pool.push_back(r.e0); ctx->ev_pool.push_back(r.e1); }
@@ -386,6 +422,7 @@ int sr_profile_begin(sr_ctx* ctx) {
 }
 
 int sr_profile_end(sr_ctx* ctx, char* json, int64_t cap) {
+    DeviceGuard dg_(ctx);
     if (!ctx || !json || cap <= 0) return SR_ERR_INVALID;
     ctx->prof = false;
     SR_HIP(ctx, hipDeviceSynchronize());
@@ -440,12 +477,63 @@ int sr_model_create(sr_ctx* ctx, int kind, const sr_model_cfg* cfg, sr_model** o
 }
 
 void sr_model_destroy(sr_model* m) {
+    DeviceGuard dg_(m ? m->ctx : nullptr);
     if (!m) return;
     (void)hipDeviceSynchronize();
     m->free_bufs();
     for (auto& c : m->convs) conv_free_weights(m->ctx, &c.w);
     for (auto& p : m->dense_dev) if (p) m->ctx->dfree(p);
     delete m;
+}
+
+int sr_model_release_workspace(sr_model* m) {
+    if (!m) return SR_ERR_INVALID;
+    DeviceGuard dg_(m->ctx);
+    SR_HIP(m->ctx, hipDeviceSynchronize());
+    m->free_bufs();
+    return SR_OK;
+}
+
+// ---- diagnostics: the op list and per-op output taps (stage-by-stage parity traces in tests/) ------------------------
+static void op_out_view(const sr_model* m, const Op& op, int* C, int* mul, int* shift) {
+    *C = 0; *mul = 1; *shift = 0;
+    if (op.out.buf < 0) return;
+    const BufSpec& b = m->bufs[op.out.buf];
+    if (b.vec) return;
+    *mul = b.mul; *shift = b.shift;
+    if (op.kind == OP_CONV) { const ConvSpec& cs = m->convs[op.conv]; *C = cs.Cout / (op.d2s * op.d2s); }
+    else if (op.kind == OP_ATTN) *C = 32;
+    else if (op.kind == OP_TOBLK) *C = 64;
+    else *C = b.C;
+}
+
+int sr_model_num_ops(sr_model* m) { return m ? (int)m->ops.size() : SR_ERR_INVALID; }
+
+int sr_model_op_info(sr_model* m, int index, const char** name, int* channels, int* mul, int* shift) {
+    if (!m || index < 0 || index >= (int)m->ops.size()) return SR_ERR_INVALID;
+    if (m->op_names.size() != m->ops.size()) {
+        m->op_names.clear();
+        static const char* kinds[] = {"convert", "conv", "attention", "maxpool", "gap", "dense", "to_blocked"};
+        for (const Op& op : m->ops)
+            m->op_names.push_back(op.kind == OP_CONV ? m->convs[op.conv].parts[0].name : std::string(kinds[op.kind]));
+    }
+    int C, mu, sh;
+    op_out_view(m, m->ops[index], &C, &mu, &sh);
+    if (name) *name = m->op_names[index].c_str();
+    if (channels) *channels = C;
+    if (mul) *mul = mu;
+    if (shift) *shift = sh;
+    return SR_OK;
+}
+
+int sr_model_set_tap(sr_model* m, int op_index, float* device_dst, int64_t capacity) {
+    if (!m || op_index < 0 || op_index >= (int)m->ops.size()) return SR_ERR_INVALID;
+    if (!device_dst) { m->taps.erase(op_index); return SR_OK; }
+    int C, mu, sh;
+    op_out_view(m, m->ops[op_index], &C, &mu, &sh);
+    if (C <= 0) return m->ctx->fail(SR_ERR_INVALID, "this op has no activation-buffer output to tap");
+    m->taps[op_index] = sr_model::Tap{device_dst, capacity};
+    return SR_OK;
 }
 
 int sr_model_num_params(sr_model* m) { return m ? (int)m->params.size() : SR_ERR_INVALID; }
@@ -475,6 +563,7 @@ int sr_model_set_weight(sr_model* m, const char* name, int which, const float* h
 }
 
 int sr_model_finalize(sr_model* m) {
+    DeviceGuard dg_(m ? m->ctx : nullptr);
     if (!m) return SR_ERR_INVALID;
     sr_ctx* ctx = m->ctx;
     for (auto& p : m->params)
@@ -520,6 +609,7 @@ int sr_model_output_shape(sr_model* m, int B, int H, int W, int C, int64_t out_s
 }
 
 int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, int C, void* y, int64_t y_capacity, void* stream) {
+    DeviceGuard dg_(m ? m->ctx : nullptr);
     if (!m) return SR_ERR_INVALID;
     sr_ctx* ctx = m->ctx;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -534,11 +624,12 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
     sr_model_output_shape(m, B, H, W, C, os);
     if (y_capacity < os[0] * os[1] * os[2] * os[3]) return ctx->fail(SR_ERR_CAPACITY, "output buffer too small");
     if (m->kind == SR_MODEL_VGG16 && (H < 32 || W < 32)) return ctx->fail(SR_ERR_INVALID, "VGG16 needs H,W >= 32");
-    int rc = ensure_workspace(m, B, H, W);
+    int rc = ensure_workspace(m, B, H, W, st);
     if (rc) return rc;
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     const int T = m->T;
-    for (const Op& op : m->ops) {
+    for (size_t oi = 0; oi < m->ops.size(); ++oi) {
+        const Op& op = m->ops[oi];
         int h = H, w = W;
         if (op.in.buf >= 0) buf_hw(m->bufs[op.in.buf], H, W, &h, &w);
         switch (op.kind) {
@@ -588,6 +679,18 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
             }
         }
         if (rc) return rc;
+        if (!m->taps.empty()) {
+            auto it = m->taps.find((int)oi);
+            if (it != m->taps.end()) {
+                int C_, mu, sh;
+                op_out_view(m, op, &C_, &mu, &sh);
+                const int th = (H * mu) >> sh, tw = (W * mu) >> sh;
+                if (it->second.cap < (int64_t)B * th * tw * C_) return ctx->fail(SR_ERR_CAPACITY, "tap buffer too small");
+                const BufSpec& ob = m->bufs[op.out.buf];
+                rc = tap_copy_launch(ctx, m->bufp[op.out.buf], T, ob.blk, ob.Cbuf, op.out.coff, B, th, tw, C_, it->second.dst, st);
+                if (rc) return rc;
+            }
+        }
     }
     SR_HIP(ctx, hipEventRecord(ctx->ev1, st));
     ctx->timed = true;
@@ -598,6 +701,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
 int sr_conv2d(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int Cin, const float* w_hwio, const float* bias, int KH, int KW,
               int Cout, int act, float alpha, const void* skip1, float beta1, const void* skip2, float beta2, int clip01, int d2s_r,
               void* y, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!x || !w_hwio || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
@@ -629,6 +733,7 @@ int sr_conv2d(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int Ci
 
 int sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, const float* wf, const float* bf, const float* wg,
                       const float* bg, const float* wh, const float* bh, const float* wv, const float* bv, void* y, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (C != 64) return ctx->fail(SR_ERR_INVALID, "SelfAttention kernel is built for channels=64 (d_qk=8, d_v=32)");
@@ -668,12 +773,14 @@ int sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W
 }
 
 int sr_bicubic(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, void* y, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     if (!x || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
     return bicubic_launch(ctx, x, dtype, B, H, W, C, outH, outW, y, dtype, C, static_cast<hipStream_t>(stream));
 }
 
 int sr_psnr(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float max_val, float* out_B, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     if (!a || !b || !out_B) return ctx->fail(SR_ERR_INVALID, "null tensor");
     return psnr_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), B, (int64_t)H * W * C, max_val, out_B,
@@ -681,6 +788,7 @@ int sr_psnr(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int 
 }
 
 int sr_ssim(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float max_val, float* out_B, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     if (!a || !b || !out_B) return ctx->fail(SR_ERR_INVALID, "null tensor");
     return ssim_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), B, H, W, C, max_val, out_B,
@@ -688,6 +796,7 @@ int sr_ssim(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int 
 }
 
 int sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     if (!a || !b || !out1) return ctx->fail(SR_ERR_INVALID, "null tensor");
     return mse_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), n, out1, static_cast<hipStream_t>(stream));
@@ -695,6 +804,7 @@ int sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, vo
 
 int sr_extract_patches(sr_ctx* ctx, const float* img, int H, int W, int C, int patch, int stride, float mul, float add, int out_dtype,
                        void* out, int64_t out_capacity, int* n_patches, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     if (H <= 0 || W <= 0 || C <= 0 || patch <= 0 || stride <= 0) return ctx->fail(SR_ERR_INVALID, "bad shape/patch/stride");
     const int ph = pad_amount(H, patch, stride), pw = pad_amount(W, patch, stride);
@@ -711,6 +821,7 @@ int sr_extract_patches(sr_ctx* ctx, const float* img, int H, int W, int C, int p
 
 int sr_overlap_add(sr_ctx* ctx, const void* patches, int in_dtype, int H, int W, int C, int patch, int stride, int scale, float mul,
                    float add, float* out, void* stream) {
+    DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;
     if (!patches || !out) return ctx->fail(SR_ERR_INVALID, "null tensor");
     if (H <= 0 || W <= 0 || C <= 0 || patch <= 0 || stride <= 0 || scale <= 0) return ctx->fail(SR_ERR_INVALID, "bad shape/patch/stride");

@@ -23,8 +23,7 @@ namespace {
 constexpr int KV_TILE = 64;
 
 template <typename T> struct AT;
-template <> struct AT<bf16_t> { [[maybe_unused]] static constexpr int PITCH = KV_TILE * 2 + 8; };    // bytes per V^T row in LDS
-template <> struct AT<float>  { static constexpr int PITCH = KV_TILE * 4 + 4; };
+template <> struct AT<float>  { static constexpr int PITCH = KV_TILE * 4 + 4; };    // bytes per V^T row in LDS
 
 struct AttnParams {
     const char* qkv; int64_t cs; int qoff, koff, voff;
@@ -34,30 +33,24 @@ struct AttnParams {
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
-template <typename T>
-__global__ void __launch_bounds__(256, 2) attn_kernel(AttnParams p) {
-    constexpr int PITCH = AT<T>::PITCH;
-    constexpr bool BF = sizeof(T) == 2;
+// fp32 kernel (reference precision): exact fp32 MFMA (32x32x2_f32) for both products, one 32-query block per wave.
+__global__ void __launch_bounds__(256, 2) attn_f32_kernel(AttnParams p) {
+    constexpr int PITCH = AT<float>::PITCH;
     __shared__ __attribute__((aligned(16))) char vt[32 * PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int N = p.N;
-    const T* base = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * N * p.cs;
+    const float* base = reinterpret_cast<const float*>(p.qkv) + (int64_t)b * N * p.cs;
     const int q = blockIdx.x * 128 + wave * 32 + r;
     const int qc = q < N ? q : N - 1;
 
     // query fragment (B operand of S^T = K.Q^T)
-    bf16x8 qb = {};
-    float qf[4] = {0.f, 0.f, 0.f, 0.f};
+    float qf[4];
     {
-        const T* qp = base + (int64_t)qc * p.cs + p.qoff;
-        if constexpr (BF) {
-            if (h == 0) qb = *reinterpret_cast<const bf16x8*>(qp);
-        } else {
+        const float* qp = base + (int64_t)qc * p.cs + p.qoff;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) qf[j] = qp[2 * j + h];
-        }
+        for (int j = 0; j < 4; ++j) qf[j] = qp[2 * j + h];
     }
 
     f32x16 oacc;
@@ -72,19 +65,12 @@ __global__ void __launch_bounds__(256, 2) attn_kernel(AttnParams p) {
         __syncthreads();   // previous tile's V^T reads are done
         {
             const int key = k0 + skey;
-            const T* vp = base + (int64_t)(key < N ? key : N - 1) * p.cs + p.voff + soct * 8;
-            if constexpr (BF) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(vp);
+            const float* vp = base + (int64_t)(key < N ? key : N - 1) * p.cs + p.voff + soct * 8;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<bf16_t*>(vt + (soct * 8 + e) * PITCH + skey * 2) = v[e];
-            } else {
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(vp), v1 = *reinterpret_cast<const f32x4*>(vp + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    *reinterpret_cast<float*>(vt + (soct * 8 + e) * PITCH + skey * 4) = v0[e];
-                    *reinterpret_cast<float*>(vt + (soct * 8 + 4 + e) * PITCH + skey * 4) = v1[e];
-                }
+            for (int e = 0; e < 4; ++e) {
+                *reinterpret_cast<float*>(vt + (soct * 8 + e) * PITCH + skey * 4) = v0[e];
+                *reinterpret_cast<float*>(vt + (soct * 8 + 4 + e) * PITCH + skey * 4) = v1[e];
             }
         }
         __syncthreads();
@@ -98,15 +84,9 @@ __global__ void __launch_bounds__(256, 2) attn_kernel(AttnParams p) {
             for (int e = 0; e < 16; ++e) s[e] = 0.f;
             {
                 const int key = kb + r;
-                const T* kp = base + (int64_t)(key < N ? key : N - 1) * p.cs + p.koff;
-                if constexpr (BF) {
-                    bf16x8 kf = {};
-                    if (h == 0) kf = *reinterpret_cast<const bf16x8*>(kp);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb, s, 0, 0, 0);
-                } else {
+                const float* kp = base + (int64_t)(key < N ? key : N - 1) * p.cs + p.koff;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * j + h], qf[j], s, 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * j + h], qf[j], s, 0, 0, 0);
             }
             // ---- online softmax over this tile's 32 keys (16 here, 16 in lane^32)
             float mx = -INFINITY;
@@ -127,43 +107,23 @@ __global__ void __launch_bounds__(256, 2) attn_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
             // ---- O^T += V^T . P^T
-            if constexpr (BF) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[8 * ks + j];
-                    const char* vrow = vt + r * PITCH + (sub * 32 + 16 * ks + 4 * h) * 2;
-                    bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow);
-                    bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + 16);
-                    bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int krow = sub * 32 + (i & 3) + 8 * (i >> 2);
-                    const float va = *reinterpret_cast<const float*>(vt + r * PITCH + (krow + 4 * h) * 4);
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s[i], oacc, 0, 0, 0);
-                }
+            for (int i = 0; i < 16; ++i) {
+                const int krow = sub * 32 + (i & 3) + 8 * (i >> 2);
+                const float va = *reinterpret_cast<const float*>(vt + r * PITCH + (krow + 4 * h) * 4);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s[i], oacc, 0, 0, 0);
             }
         }
     }
     const float l_tot = l_run + xhalf(l_run);
     const float inv = 1.f / l_tot;
     if (q < N) {
-        T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * N + q) * p.o_cs + p.o_coff;
+        float* op = reinterpret_cast<float*>(p.o) + ((int64_t)b * N + q) * p.o_cs + p.o_coff;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d0 = 8 * g + 4 * h;
-            if constexpr (BF) {
-                bf16x4 t = {(bf16_t)(oacc[4 * g] * inv), (bf16_t)(oacc[4 * g + 1] * inv), (bf16_t)(oacc[4 * g + 2] * inv),
-                            (bf16_t)(oacc[4 * g + 3] * inv)};
-                *reinterpret_cast<bf16x4*>(op + d0) = t;
-            } else {
-                f32x4 t = {oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
-                *reinterpret_cast<f32x4*>(op + d0) = t;
-            }
+            f32x4 t = {oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + d0) = t;
         }
     }
 }
@@ -445,7 +405,7 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
         const int64_t nwg = (int64_t)B * ((N + 255) / 256);
         hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, p);
     }
-    else hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, st, p);
     ctx->prof_close(rec, st);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/sr355.h"
@@ -39,10 +40,27 @@ struct sr_ctx {
     int prof_open(const std::string& name, double flops, double bytes, hipStream_t st);
     void prof_close(int rec, hipStream_t st);
 
+    // kernels whose dynamic-LDS ceiling has been raised on THIS context's device (hipFuncSetAttribute is per device)
+    std::unordered_set<const void*> lds_attr_done;
+    int ensure_dyn_lds(const void* kernel, int bytes);
+    int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
+
     void* dalloc(size_t bytes);   // nullptr on failure (err set)
     void dfree(void* p);
     void* scratch(size_t bytes);  // reduction scratch; stream-ordered reuse (one stream per ctx at a time)
     int fail(int code, const std::string& msg) { err = msg; return code; }
+};
+
+// Every ABI entry that allocates or launches binds the calling thread to the context's device first and puts the
+// previous device back on return (the current device is per-thread state the caller -- torch -- may have changed).
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(const sr_ctx* c) {
+        if (c && hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
 #define SR_HIP(ctx, call)                                                                        \
@@ -114,6 +132,8 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
 // [B,H,W,C] of in_dtype -> [B,H,W,Cp] of out_dtype, channels >= C zero-filled, v*mul+add on real ones.
 int nhwc_to_blocked_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C,
                            int dst_coff, hipStream_t st);
+int clock_probe_launch(sr_ctx* ctx, float* mhz_out, hipStream_t st);
+int tap_copy_launch(sr_ctx* ctx, const void* src, int dtype, int blk, int64_t cs, int coff, int B, int H, int W, int C, float* dst, hipStream_t st);
 int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype,
                        int Cp, float mul, float add, hipStream_t st);
 int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y,

@@ -254,11 +254,7 @@ int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     p.tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 8 * MT - 1) / (8 * MT);
     auto kern = conv_wide_kernel<T, KS, KGPT, NT, MT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     SR_HIP(ctx, hipGetLastError());
@@ -275,11 +271,7 @@ int launch_thin(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     p.tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 8 * MT - 1) / (8 * MT);
     auto kern = conv_thin_kernel<T, KS, NT, MT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     SR_HIP(ctx, hipGetLastError());

@@ -126,15 +126,18 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
     // LDS layout, 1 KiB per wave-instruction): no VGPR round trip and none of the ds_write_b128 traffic (36 KB per chunk at 64
     // couts) through the VGPR -> LDS path.  Issued after the barrier that frees the weight buffer, landed by land_all()'s wait.
     constexpr bool WDMA = !WPRE;
+    // Every wave issues exactly DMA_PER_WAVE instructions -- the counted vmcnt wait below relies on that number, and
+    // tools/check_prefetch_hazards.py proves it on the control-flow graph: no branch around an issue.  Where the piece count is not a
+    // multiple of 4 (18 pieces at 32 couts) the waves that run out re-fetch the last piece: same bytes to the same LDS address.
+    constexpr int PIECES = WUNITS / 64, DMA_PER_WAVE = (PIECES + 3) / 4;
     auto dma_w = [&](int chunk) {
         const char* wsrc = wbase + (int64_t)chunk * (WUNITS * 16);
         const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-        for (int i = 0; i < (WUNITS / 64 + 3) / 4; ++i) {
-            const int piece = wv + 4 * i;                    // wave-uniform
-            if (piece < WUNITS / 64)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ((size_t)piece * 64 + lane) * 16),
-                                                 (__attribute__((address_space(3))) void*)(lw + piece * 1024), 16, 0, 0);
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int piece = min(wv + 4 * i, PIECES - 1);   // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ((size_t)piece * 64 + lane) * 16),
+                                             (__attribute__((address_space(3))) void*)(lw + piece * 1024), 16, 0, 0);
         }
     };
     auto land_all = [&]() {   // wait for every asm load in flight; "+v" on each destination orders all their uses behind the wait
@@ -180,9 +183,7 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
             // the weight DMA just issued is younger than the input prefetch (issued a whole compute phase ago): wait for all but
             // this wave's DMA instructions (vmcnt counts in order), write the input image while the weights are still in flight
             dma_w(chunk);
-            constexpr int PIECES = WUNITS / 64, Q = PIECES / 4, REM = PIECES % 4;
-            if (REM != 0 && __builtin_amdgcn_readfirstlane(wave) < REM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
 #pragma unroll
             for (int i = 0; i < NINT; ++i) asm volatile("" : "+v"(pre[i]));
         } else {
@@ -244,6 +245,9 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
             }
         }
     }
+    // nothing may be in flight past this point (there is not, on any path the host can produce: the last chunk issues no prefetch
+    // and nchunks >= 1) -- stated as an instruction so that the hazard checker can prove it path-insensitively; free when idle
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP_AT(14);
 
     // ---- epilogue (conv_rows_epi.h)
@@ -278,17 +282,13 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     dim3 grid((unsigned)nwg, 1u);
     if (p.dbg) {   // diagnostic stamped variant
         auto kd = conv3_rows_kernel<NB16, R, true>;
-        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kd), lds)) return rc;
         hipLaunchKernelGGL(kd, grid, dim3(256), lds, st, p);
         SR_HIP(ctx, hipGetLastError());
         return SR_OK;
     }
     auto kern = conv3_rows_kernel<NB16, R, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;

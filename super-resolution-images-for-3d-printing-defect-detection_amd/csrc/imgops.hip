@@ -3,6 +3,7 @@
 // extraction with reflect padding, overlap-add reconstruction, max-pool, global average pool,
 // dense head + softmax.  Each is priced against HBM bytes in DESIGN.md; none is GEMM-shaped.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -459,6 +460,29 @@ int nhwc_to_blocked_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src
     return SR_OK;
 }
 
+// Diagnostic tap (sr_model_set_tap): channels [coff, coff + C) of an activation buffer -- NHWC or row-blocked, bf16 or fp32 -- as a dense
+// fp32 NHWC tensor.  One thread per element; never on a timed path.
+__global__ void tap_copy_kernel(const void* src, int dtype, int blk, int64_t cs, int coff, int64_t rows, int W, int C, float* dst) {
+    const int64_t n = rows * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % W);
+        const int64_t row = pix / W;
+        const int ch = coff + c;
+        const int64_t e = blk ? row * W * cs + (int64_t)(ch >> 5) * W * 32 + x * 32 + (ch & 31) : pix * cs + ch;
+        dst[i] = dtype == SR_DTYPE_BF16 ? (float)static_cast<const bf16_t*>(src)[e] : static_cast<const float*>(src)[e];
+    }
+}
+
+int tap_copy_launch(sr_ctx* ctx, const void* src, int dtype, int blk, int64_t cs, int coff, int B, int H, int W, int C, float* dst, hipStream_t st) {
+    const int64_t n = (int64_t)B * H * W * C;
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(tap_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, src, dtype, blk, cs, coff, (int64_t)B * H, W, C, dst);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
 int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype, int Cp, float mul,
                        float add, hipStream_t st) {
     if (npix <= 0) return SR_OK;
@@ -580,5 +604,58 @@ int overlap_add_launch(sr_ctx* ctx, const void* patches, int in_dtype, int H, in
     hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, patches, in_dtype, H, W, C, patch, stride, scale, mul, add,
                        ny, nx, out);
     SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Clock probe (sr_measure_clock): the shader clock the chip holds under a dense bf16 MFMA load, from
+// delta(s_memtime) / delta(s_memrealtime) x 100 MHz around an MFMA loop (MI355X_MICROARCH.md, DVFS give-back item 6).
+// bench.py prices its roofline peak at this clock beside the nominal one.  Stamps go to a buffer nothing else reads.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) clock_probe_kernel(unsigned long long* stamps, float* sink, int iters, unsigned seed) {
+    const int lane = threadIdx.x & 63;
+    unsigned s = seed ^ (blockIdx.x * 2654435761u) ^ (threadIdx.x * 40503u);
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s = s * 1664525u + 1013904223u; a[i] = (bf16_t)((float)((s >> 9) & 0xffff) * (1.f / 65536.f) - 0.5f);
+        s = s * 1664525u + 1013904223u; b[i] = (bf16_t)((float)((s >> 9) & 0xffff) * (1.f / 65536.f) - 0.5f);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (v == 123.456f) sink[0] = v;                       // keeps the MFMAs alive; never true in practice
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    (void)lane;
+}
+
+int clock_probe_launch(sr_ctx* ctx, float* mhz_out, hipStream_t st) {
+    const int nblk = 1024, iters = 4000;                  // 1024 workgroups x 4 waves x 128k MFMAs: ~2 ms per launch
+    unsigned long long* d = static_cast<unsigned long long*>(ctx->dalloc(sizeof(unsigned long long) * 2 * nblk + sizeof(float)));
+    if (!d) return SR_ERR_OOM;
+    float* sink = reinterpret_cast<float*>(d + 2 * nblk);
+    for (int rep = 0; rep < 150; ++rep)                   // ~0.3 s of back-to-back load before the launch that is read
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(nblk), dim3(256), 0, st, d, sink, iters, 12345u + rep);
+    std::vector<unsigned long long> h(2 * nblk);
+    hipError_t e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 2 * nblk, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    ctx->dfree(d);
+    if (e != hipSuccess) return ctx->fail(SR_ERR_HIP, std::string("clock probe: ") + hipGetErrorString(e));
+    std::vector<double> f;
+    for (int i = 0; i < nblk; ++i) if (h[2 * i + 1] > 0) f.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
+    if (f.empty()) return ctx->fail(SR_ERR_HIP, "clock probe: no stamps");
+    std::sort(f.begin(), f.end());
+    *mhz_out = (float)f[f.size() / 2];
     return SR_OK;
 }

@@ -35,10 +35,16 @@ SIGNATURES = {
     "sr_mem_info": (_i, [_vp, _i64p, _i64p]),
     "sr_last_forward_ms": (_i, [_vp, _fp]),
     "sr_debug_set_stamp_buffer": (_i, [_vp, _vp]),
+    "sr_measure_clock": (_i, [_vp, _fp, _vp]),
+    "sr_debug_set_alloc_cap": (_i, [_vp, _i64]),
     "sr_profile_begin": (_i, [_vp]),
     "sr_profile_end": (_i, [_vp, C.c_char_p, _i64]),
     "sr_model_create": (_i, [_vp, _i, C.POINTER(ModelCfg), C.POINTER(_vp)]),
     "sr_model_destroy": (None, [_vp]),
+    "sr_model_release_workspace": (_i, [_vp]),
+    "sr_model_num_ops": (_i, [_vp]),
+    "sr_model_op_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "sr_model_set_tap": (_i, [_vp, _i, _vp, _i64]),
     "sr_model_num_params": (_i, [_vp]),
     "sr_model_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), _i64p, C.POINTER(_i)]),
     "sr_model_set_weight": (_i, [_vp, C.c_char_p, _i, _fp, _i64p, _i]),

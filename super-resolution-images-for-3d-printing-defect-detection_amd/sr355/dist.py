@@ -29,11 +29,51 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def partition_tiles(n_tiles, rank, world, scaling="strong"):
+    """"strong" = ONE batch of n_tiles split B/g over the ranks in contiguous slices (16 tiles -> 16/8/4/2 per GPU
+    at 1/2/4/8 GPUs); "weak" = every rank owns n_tiles of its own.  -> (tile ids of this rank, tiles of the whole job)."""
+    if scaling == "weak":
+        return list(range(n_tiles)), n_tiles * world
+    if scaling != "strong":
+        raise ValueError(f"scaling must be 'strong' or 'weak', not {scaling!r}")
+    lo, hi = shard_range(n_tiles, rank, world)
+    return list(range(lo, hi)), n_tiles
+
+
+def _allreduce(t, op):
+    """In-place all-reduce of a small tensor.  RCCL ("nccl") reduces device tensors directly; under gloo (CPU tests, and the
+    N>1 rehearsal of bench.py on a one-GPU box) a device tensor is staged through the host."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    if t.is_cuda and dist.get_backend() != "nccl":
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def allreduce_metric_sums(sums):
-    """sums: float64 tensor [sum_psnr, sum_ssim, count] on this rank's device -> global sums (in place)."""
+    """sums: float64 tensor [sum_psnr, sum_ssim, count] on this rank's device -> global sums (in place).  The path's only
+    exchange step."""
+    return _allreduce(sums, dist.ReduceOp.SUM)
+
+
+def allreduce_max(t):
+    """max over ranks, in place (bench.py: the slowest rank's wall time)."""
+    return _allreduce(t, dist.ReduceOp.MAX)
+
+
+def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    return sums
+        dist.barrier()
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def mean_metrics(sums):

@@ -38,6 +38,20 @@ def _np32(a):
     return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
 
+def _check_tensor(ctx, t, name, dtypes=(torch.float32,)):
+    """The kernels read raw device pointers: a tensor handed over the ABI must live on the context's GPU, be dense and have
+    a dtype the entry point understands.  Anything else raises ValueError here instead of reading out of bounds there."""
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a torch tensor on {ctx.torch_device}")
+    if t.device != ctx.torch_device:
+        raise ValueError(f"{name}: tensor is on {t.device}, the context drives {ctx.torch_device}")
+    if t.dtype not in dtypes:
+        raise ValueError(f"{name}: dtype {t.dtype} not supported here (expected one of {[str(d) for d in dtypes]})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
 class Context:
     """sr_ctx wrapper; `Context.get(i)` returns the process-wide context of GPU i."""
     _instances = {}
@@ -93,6 +107,16 @@ class Context:
         self.check(self.lib.sr_last_forward_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def measure_clock_mhz(self):
+        """Shader clock held under a dense bf16 MFMA load (in-kernel s_memtime / s_memrealtime), MHz."""
+        mhz = C.c_float()
+        self.check(self.lib.sr_measure_clock(self.h, C.byref(mhz), self.stream()))
+        return mhz.value
+
+    def set_alloc_cap(self, nbytes):
+        """Test hook: allocations through this context fail once it would hold more than nbytes (0 = no cap)."""
+        self.check(self.lib.sr_debug_set_alloc_cap(self.h, int(nbytes)))
+
     def profile_begin(self):
         self.check(self.lib.sr_profile_begin(self.h))
 
@@ -110,6 +134,10 @@ class Context:
         w = _np32(w)
         b = _np32(b)
         kh, kw, cin, cout = w.shape
+        _check_tensor(self, x, "conv2d input", (torch.float32, torch.bfloat16))
+        for nm, sk in (("skip1", skip1), ("skip2", skip2)):
+            if sk is not None:
+                _check_tensor(self, sk, f"conv2d {nm}", (x.dtype,))
         B, H, W, Cx = x.shape
         if Cx != cin:
             raise ValueError("conv2d: input channels do not match the kernel")
@@ -123,6 +151,7 @@ class Context:
         return y
 
     def self_attention(self, x, wf, bf, wg, bg, wh, bh, wv, bv):
+        _check_tensor(self, x, "self_attention input", (torch.float32, torch.bfloat16))
         B, H, W, Cx = x.shape
         arrs = [_np32(a) for a in (wf, bf, wg, bg, wh, bh, wv, bv)]
         y = torch.empty_like(x)
@@ -131,6 +160,7 @@ class Context:
         return y
 
     def bicubic(self, x, out_h, out_w):
+        _check_tensor(self, x, "bicubic input", (torch.float32, torch.uint8))
         B, H, W, Cx = x.shape
         y = self.empty((B, out_h, out_w, Cx), x.dtype)
         self.check(self.lib.sr_bicubic(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, Cx, int(out_h), int(out_w), y.data_ptr(),
@@ -138,6 +168,8 @@ class Context:
         return y
 
     def _metric(self, fn, a, b, max_val):
+        _check_tensor(self, a, "metric input a")
+        _check_tensor(self, b, "metric input b")
         if a.shape != b.shape or a.dim() != 4:
             raise ValueError("metric inputs must be two [B,H,W,C] tensors of the same shape")
         B, H, W, Cx = a.shape
@@ -153,6 +185,10 @@ class Context:
         return self._metric(self.lib.sr_ssim, a, b, max_val)
 
     def mse(self, a, b):
+        _check_tensor(self, a, "mse input a")
+        _check_tensor(self, b, "mse input b")
+        if a.shape != b.shape:
+            raise ValueError("mse inputs must have the same shape")
         out = self.empty((1,), torch.float32)
         self.check(self.lib.sr_mse(self.h, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), self.stream()))
         return out
@@ -163,6 +199,7 @@ class Context:
         return n.value
 
     def extract_patches(self, img, patch, stride, mul=1.0, add=0.0, out_dtype=torch.float32):
+        _check_tensor(self, img, "extract_patches image")
         H, W, Cx = img.shape
         n = self.num_patches(H, W, Cx, patch, stride)
         out = self.empty((n, patch, patch, Cx), out_dtype)
@@ -172,6 +209,7 @@ class Context:
         return out
 
     def overlap_add(self, patches, H, W, patch, stride, scale=1, mul=1.0, add=0.0):
+        _check_tensor(self, patches, "overlap_add patches", (torch.float32, torch.bfloat16))
         Cx = patches.shape[-1]
         out = self.empty((H * scale, W * scale, Cx), torch.float32)
         self.check(self.lib.sr_overlap_add(self.h, patches.data_ptr(), dtype_code(patches.dtype), H, W, Cx, patch, stride, scale,
@@ -243,15 +281,58 @@ class Model:
 
     def forward(self, x, out=None):
         """x [B,H,W,C] device tensor (f32, or bf16 for a bf16 model) -> output tensor of the same dtype."""
-        if x.dim() != 4:
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise ValueError("expected a [B,H,W,C] tensor")
         x = x.contiguous()
+        _check_tensor(self.ctx, x, "forward input", (torch.float32, torch.bfloat16))
         B, H, W, Cx = x.shape
         oshape = self.output_shape(B, H, W, Cx)
+        if out is not None:
+            _check_tensor(self.ctx, out, "forward out=", (x.dtype,))
+            if tuple(out.shape) != tuple(oshape):
+                raise ValueError(f"forward out= has shape {tuple(out.shape)}, the model produces {tuple(oshape)}")
         y = out if out is not None else self.ctx.empty(oshape, x.dtype)
         self.ctx.check(self.ctx.lib.sr_forward(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, Cx, y.data_ptr(), y.numel(),
                                                self.ctx.stream()))
         return y
+
+    # ------------------------------------------------------------------ workspaces / diagnostics
+    def release_workspace(self):
+        """Free the activation workspaces (grow-only otherwise); weights stay loaded."""
+        self.ctx.check(self.ctx.lib.sr_model_release_workspace(self.h))
+
+    def ops(self):
+        """[(name, channels, mul, shift)] per graph op: Keras layer name of a conv, else the op kind; the op's output is
+        [B, (H*mul)>>shift, (W*mul)>>shift, channels] (channels 0: no activation output)."""
+        lib, out = self.ctx.lib, []
+        for i in range(lib.sr_model_num_ops(self.h)):
+            name, ch, mul, sh = C.c_char_p(), C.c_int(), C.c_int(), C.c_int()
+            self.ctx.check(lib.sr_model_op_info(self.h, i, C.byref(name), C.byref(ch), C.byref(mul), C.byref(sh)))
+            out.append((name.value.decode(), ch.value, mul.value, sh.value))
+        return out
+
+    def forward_with_taps(self, x, names):
+        """Diagnostic forward: -> (y, {name: fp32 NHWC tensor}) with the output of the LAST op called `name` for every name
+        (stage-by-stage parity traces; the taps are removed again before returning)."""
+        ops = self.ops()
+        B, H, W, _ = x.shape
+        taps, idx = {}, {}
+        for n in names:
+            hits = [i for i, o in enumerate(ops) if o[0] == n and o[1] > 0]
+            if not hits:
+                raise KeyError(f"no op named '{n}' with an activation output")
+            idx[n] = hits[-1]
+        try:
+            for n, i in idx.items():
+                _, ch, mul, sh = ops[i]
+                t = self.ctx.empty((B, (H * mul) >> sh, (W * mul) >> sh, ch), torch.float32)
+                self.ctx.check(self.ctx.lib.sr_model_set_tap(self.h, i, t.data_ptr(), t.numel()))
+                taps[n] = t
+            y = self.forward(x)
+        finally:
+            for i in idx.values():
+                self.ctx.lib.sr_model_set_tap(self.h, i, None, 0)
+        return y, taps
 
     def predict(self, x, batch_size=32):
         """keras Model.predict(x, batch_size): forward in chunks, outputs concatenated.  Accepts NumPy

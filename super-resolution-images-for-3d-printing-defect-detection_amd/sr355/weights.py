@@ -29,6 +29,20 @@ def init_weights(layer_shapes, scheme="glorot_uniform", seed=1000, bias_range=0.
     return out
 
 
+def condition_attention(weights, shift=4):
+    """Scale the SelfAttention query/key projections (`*_f`, `*_g`: kernel and bias) by 2**-shift -- exact in bf16.
+
+    Why the synthetic weights need it: the reference's SelfAttention has no 1/sqrt(d) scale (ESRGAN_model.py:61-65) and its
+    RRDB graph has a gain of 1.2 per block even with zero convs (rrdb_in + 0.2*(x + ...), ESRGAN_model.py:249-281), i.e.
+    1.2**23 = 66x at the default depth.  With untrained glorot weights the softmax logits then span about +-1700: a hard
+    argmax, where the output image depends on the last bit of ANY arithmetic (the CPU oracle evaluated in fp32 and in fp64
+    agree to only 11 dB PSNR).  With the logits brought to O(1) -- where a trained network keeps them -- the graph is
+    well conditioned (oracle fp32 vs fp64: > 100 dB; bf16 storage noise floor: ~49 dB) and a parity number means
+    something.  shift=4 scales the logits by 2**-8."""
+    g = np.float32(2.0 ** -int(shift))
+    return {n: ((k * g, b * g) if (n.endswith("_f") or n.endswith("_g")) else (k, b)) for n, (k, b) in weights.items()}
+
+
 def round_to_bf16(a):
     """Round-to-nearest-even fp32 -> bf16 -> fp32 (what the device does when it packs weights)."""
     a = np.ascontiguousarray(a, dtype=np.float32)

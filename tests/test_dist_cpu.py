@@ -31,11 +31,29 @@ def _worker(rank, world, port, n_units, q):
         sums[2] = hi - lo
     D.allreduce_metric_sums(sums)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)          # bench.py's max-over-ranks of the elapsed time
+    D.allreduce_max(t)                                # bench.py's max-over-ranks of the elapsed time
+    mine, total = D.partition_tiles(16, r, w, "strong")
+    cnt = torch.tensor([float(len(mine)), float(sum(mine))], dtype=torch.float64)
+    D.allreduce_metric_sums(cnt)                      # every tile of the batch owned by exactly one rank
+    assert total == 16 and cnt.tolist() == [16.0, float(sum(range(16)))]
+    D.barrier()
     if rank == 0:
         q.put((D.mean_metrics(sums), float(t.item())))
-    dist.barrier()
-    dist.destroy_process_group()
+    D.shutdown()
+
+
+def test_partition_tiles():
+    """16 tiles -> 16/8/4/2 per GPU at 1/2/4/8 GPUs; weak = 16 each."""
+    from sr355 import dist as D
+    for world in (1, 2, 4, 8):
+        owned = [D.partition_tiles(16, r, world, "strong") for r in range(world)]
+        assert all(t == 16 for _, t in owned) and all(len(m) == 16 // world for m, _ in owned)
+        assert sorted(i for m, _ in owned for i in m) == list(range(16))
+    assert D.partition_tiles(16, 3, 8, "weak") == (list(range(16)), 128)
+    assert [len(D.partition_tiles(16, r, 3, "strong")[0]) for r in range(3)] == [6, 5, 5]
+    import pytest
+    with pytest.raises(ValueError):
+        D.partition_tiles(16, 0, 2, "diagonal")
 
 
 def test_two_rank_metric_allreduce():

@@ -106,3 +106,21 @@ def test_vote_and_shards():
         spans = [shard_range(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_tensor_checks_in_front_of_the_abi():
+    """sr355.runtime._check_tensor: device, dtype and contiguity are checked on the host before a raw pointer crosses the ABI."""
+    from types import SimpleNamespace
+    import torch
+    from sr355.runtime import _check_tensor
+    fake = SimpleNamespace(torch_device=torch.device("cpu"))
+    t = torch.zeros(2, 4, 4, 3)
+    assert _check_tensor(fake, t, "x") is t
+    with pytest.raises(ValueError):
+        _check_tensor(fake, t.to(torch.bfloat16), "x")
+    with pytest.raises(ValueError):
+        _check_tensor(fake, t[:, ::2], "x")
+    with pytest.raises(ValueError):
+        _check_tensor(fake, t.numpy(), "x")
+    with pytest.raises(ValueError):
+        _check_tensor(SimpleNamespace(torch_device=torch.device("meta")), t, "x")

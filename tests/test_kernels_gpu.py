@@ -1,8 +1,10 @@
 """Kernel-level parity: HIP ops called through the C ABI vs the CPU oracle on seeded inputs.
 
-Tolerances: fp32 kernels (exact-fp32 MFMA fma chains) rel-L2 <= 1e-5 against the fp32 oracle
-(SURVEY.md 8d); bf16 kernels are compared with the fp32 oracle evaluated on bf16-rounded
-weights/inputs, rel-L2 <= 1e-2 per op (one bf16 rounding of the output, fp32 accumulation).
+Tolerances: fp32 kernels (exact-fp32 MFMA fma chains) rel-L2 <= 1e-5 against the fp64 oracle
+(SURVEY.md 8d).  bf16 kernels: operands are bf16-exact, the oracle's fp64 result is rounded to
+bf16 where the device stores bf16 (oracle.ops.round_bf16), so all that may differ is an
+accumulation-order flip across a rounding boundary: every element within one bf16 ulp
+(2^-7 relative, plus an absolute floor for cancelled sums) and rel-L2 <= 1e-3.
 """
 import numpy as np
 import pytest
@@ -18,6 +20,17 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def assert_bf16_close(got, ref, scale=1.0, rel=1e-3):
+    """got: device bf16 result (as fp32); ref: fp64 oracle BEFORE the storage rounding."""
+    refq = O.round_bf16(np.asarray(ref, np.float64))
+    d = np.abs(np.asarray(got, np.float64) - refq)
+    bound = 2.0 ** -7 * np.abs(refq) + 3e-5 * scale
+    bad = d > bound
+    assert not bad.any(), (int(bad.sum()), float(d.max()), float((d / bound).max()))
+    err = rel_l2(got, refq)
+    assert err <= rel, err
 
 
 def _dev(ctx, a, dtype):
@@ -41,6 +54,9 @@ CONV_CASES = [
     (1, 13, 21, 32, 64, 1, "linear"),    # attention output conv (4 cout blocks x 1 chunk), ragged 16-pixel segments
     (2, 7, 40, 128, 16, 1, "lrelu"),     # 1x1, 1 cout block x 4 chunks
     (1, 5, 5, 160, 64, 1, "relu"),       # 1x1 too wide for the register-resident kernel: first-generation path
+    (2, 48, 48, 32, 32, 3, "lrelu"),     # single 32-channel chunk on conv_rows (EDSR num_filters=32; the shape of round 1's probe fault)
+    (3, 21, 35, 32, 64, 3, "relu"),      # single chunk, 64 couts per workgroup (36 weight DMA pieces), ragged tiles
+    (1, 16, 16, 32, 16, 3, "linear"),    # single chunk, one 16-cout block (register-prefetched weights)
 ]
 
 
@@ -58,8 +74,11 @@ def test_conv2d_matches_oracle(ctx, case, dtype):
     ref = O.conv2d(x, w, b, act=act, dtype=np.float64)
     got = ctx.conv2d(_dev(ctx, x, td), w, b, act=act).float().cpu().numpy()
     assert got.shape == ref.shape
-    err = rel_l2(got, ref)
-    assert err <= (1e-5 if dtype == "f32" else 1e-2), err
+    if dtype == "f32":
+        err = rel_l2(got, ref)
+        assert err <= 1e-5, err
+    else:
+        assert_bf16_close(got, ref)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -77,7 +96,10 @@ def test_conv2d_epilogue_skips_clip(ctx, dtype):
     ref = np.clip(0.04 * O.conv2d(x, w, b, dtype=np.float64) + s1 + 0.2 * s2, 0, 1)
     got = ctx.conv2d(_dev(ctx, x, td), w, b, alpha=0.04, skip1=_dev(ctx, s1, td), beta1=1.0, skip2=_dev(ctx, s2, td), beta2=0.2,
                      clip01=True).float().cpu().numpy()
-    assert rel_l2(got, ref) <= (1e-5 if dtype == "f32" else 1e-2)
+    if dtype == "f32":
+        assert rel_l2(got, ref) <= 1e-5
+    else:
+        assert_bf16_close(got, ref)
 
 
 def test_conv1x1_with_skips(ctx):
@@ -92,9 +114,9 @@ def test_conv1x1_with_skips(ctx):
     conv = O.conv2d(o, w, b, dtype=np.float64)
     od, d1, d2 = (_dev(ctx, a, torch.bfloat16) for a in (o, s1, s2))
     got1 = ctx.conv2d(od, w, b, skip1=d1, beta1=1.0).float().cpu().numpy()
-    assert rel_l2(got1, conv + s1) <= 1e-2
+    assert_bf16_close(got1, conv + s1)
     got2 = ctx.conv2d(od, w, b, alpha=0.5, skip1=d1, beta1=1.0, skip2=d2, beta2=0.2).float().cpu().numpy()
-    assert rel_l2(got2, 0.5 * conv + s1 + 0.2 * s2) <= 1e-2
+    assert_bf16_close(got2, 0.5 * conv + s1 + 0.2 * s2)
 
 
 @pytest.mark.parametrize("which", [1, 2])
@@ -116,7 +138,7 @@ def test_conv2d_skip_is_own_input(ctx, hw, which):
     else:               # RRDB tail: another tensor is skip 1, x is skip 2
         ref = 0.04 * conv + other + 0.2 * x
         got = ctx.conv2d(xd, w, b, alpha=0.04, skip1=od, beta1=1.0, skip2=xd, beta2=0.2)
-    assert rel_l2(got.float().cpu().numpy(), ref) <= 1e-2
+    assert_bf16_close(got.float().cpu().numpy(), ref)
     # and against the same op with the skip passed as a separate copy (HBM path): equal up to one bf16 ulp of fp32 re-association
     xc = xd.clone()
     got2 = ctx.conv2d(xd, w, b, alpha=0.2, skip1=xc, beta1=1.0) if which == 1 else \
@@ -138,6 +160,12 @@ def test_conv2d_depth_to_space_dcr(ctx, r, cout):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+# bf16 attention vs oracle.ops.self_attention_bf16_storage (f/g/h, the probabilities and the output rounded to bf16 where the kernel
+# rounds them).  What remains: the kernel takes probabilities relative to a possibly stale running max (another rounding draw of the
+# same 2^-9 size) and accumulates in fp32.
+BF16_ATTN_TOL = 4e-3
+
+
 def _sa_weights(rng, C=64):
     mk = lambda ci, co: (rng.standard_normal((1, 1, ci, co)) / np.sqrt(ci)).astype(np.float32)
     bias = lambda co: rng.uniform(-0.1, 0.1, co).astype(np.float32)
@@ -155,10 +183,10 @@ def test_self_attention_matches_oracle(ctx, hw, dtype):
     if dtype == "bf16":
         x = round_to_bf16(x)
         ws = [round_to_bf16(a) if a.ndim == 4 else a for a in ws]
-    ref = O.self_attention(x, *ws, dtype=np.float64)
+    ref = (O.self_attention if dtype == "f32" else O.self_attention_bf16_storage)(x, *ws, dtype=np.float64)
     got = ctx.self_attention(_dev(ctx, x, td), *ws).float().cpu().numpy()
     err = rel_l2(got, ref)
-    assert err <= (2e-5 if dtype == "f32" else 2e-2), err
+    assert err <= (2e-5 if dtype == "f32" else BF16_ATTN_TOL), err
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -176,10 +204,10 @@ def test_self_attention_forced_max_jump(ctx, spike, dtype):
     if dtype == "bf16":
         x = round_to_bf16(x)
         ws = [round_to_bf16(a) if a.ndim == 4 else a for a in ws]
-    ref = O.self_attention(x, *ws, dtype=np.float64)
+    ref = (O.self_attention if dtype == "f32" else O.self_attention_bf16_storage)(x, *ws, dtype=np.float64)
     got = ctx.self_attention(_dev(ctx, x, td), *ws).float().cpu().numpy()
     assert np.isfinite(got).all()
-    assert rel_l2(got, ref) <= (2e-5 if dtype == "f32" else 3e-2), rel_l2(got, ref)
+    assert rel_l2(got, ref) <= (2e-5 if dtype == "f32" else BF16_ATTN_TOL), rel_l2(got, ref)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -199,11 +227,12 @@ def test_self_attention_large_uniform_scores(ctx, sign, dtype):
     if dtype == "bf16":
         x = round_to_bf16(x)
         ws = [round_to_bf16(a) if a.ndim == 4 else a for a in ws]
-    ref = O.self_attention(x, *ws, dtype=np.float64)
+    ref = (O.self_attention if dtype == "f32" else O.self_attention_bf16_storage)(x, *ws, dtype=np.float64)
     got = ctx.self_attention(_dev(ctx, x, td), *ws).float().cpu().numpy()
     assert np.isfinite(got).all()
-    # bf16: k and q are rounded to bf16 after the projection, so scores of magnitude 400 carry errors of order 1 -- compare loosely
-    assert rel_l2(got, ref) <= (2e-5 if dtype == "f32" else 1.5e-1), rel_l2(got, ref)
+    # bf16: k and q are rounded to bf16 after the projection, so scores of magnitude 400 carry errors of order 1 -- the bf16-storage
+    # restatement of the oracle rounds them at the same place, which is what lets this bound be the ordinary one
+    assert rel_l2(got, ref) <= (2e-5 if dtype == "f32" else BF16_ATTN_TOL), rel_l2(got, ref)
 
 
 # ------------------------------------------------------------------------------------------------ image ops

@@ -163,18 +163,18 @@ def test_whole_image_attention_sampled_rows(ctx):
 
 def test_full_depth_generator_bf16_tracks_fp32(ctx):
     """The bench generator at full depth (ESRGAN x4, NB=23, G=32, both SelfAttention layers) in reference patch mode: the bf16 path
-    against the library's own fp32 path (itself pinned to the oracle at <= 1e-5 by the kernel tests).  With random weights the
-    23 RRDBs drive attention scores far from zero, which is where a softmax or a skip path goes wrong first; a second call on
+    against the library's own fp32 path (both pinned to the oracle at full depth by tests/test_full_depth_gpu.py), on the
+    attention-conditioned synthetic weights (sr355.weights.condition_attention); a second call on
     the same tile must give the same image (nothing may leak from one forward into the next through the workspaces)."""
     from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
-    from sr355.weights import init_weights
+    from sr355.weights import condition_attention, init_weights
     lr4, hr4 = make_pairs(1, 168, 168, 4, seed=44)                # 168 = 7 strides of 24 -> 6 x 6 = 36 patches of 48
     lr, hr = ctx.to_device(lr4), ctx.to_device(hr4)
     out = {}
     for dt in ("f32", "bf16"):
         m = ESRGAN(compute_dtype=dt)
         m.setup_model(scale_factor=4, growth_channels=32, num_rrdb_blocks=23, use_attention=True)
-        m.set_weights(init_weights(m.generator.layer_shapes(), seed=3000))
+        m.set_weights(condition_attention(init_weights(m.generator.layer_shapes(), seed=3000)))
         sr = m.super_resolve_image(lr[0], patch_size_lr=48, stride=24, batch_size=64)[0]
         sr2 = m.super_resolve_image(lr[0], patch_size_lr=48, stride=24, batch_size=64)[0]
         assert torch.isfinite(sr).all()
@@ -182,5 +182,7 @@ def test_full_depth_generator_bf16_tracks_fp32(ctx):
         out[dt] = (sr, float(ctx.psnr(hr, sr[None])[0]))
         del m
     d = float(ctx.psnr(out["f32"][0][None], out["bf16"][0][None])[0])
-    assert d >= 20.0, d                                           # measured ~26 dB: the random-weight net amplifies bf16 rounding
+    # both paths are pinned to the oracle at full depth in tests/test_full_depth_gpu.py (bf16 storage noise floor there: ~49 dB per
+    # patch); here the whole patch-mode pipeline, overlap-averaged
+    assert d >= 40.0, d
     assert abs(out["f32"][1] - out["bf16"][1]) <= 0.02, (out["f32"][1], out["bf16"][1])   # PSNR vs HR: north-star bar is 0.01 dB on trained nets
