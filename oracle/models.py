@@ -85,6 +85,111 @@ def discriminator_layers():
     return L + [("disc_dense1", (256, 256)), ("disc_output", (256, 1))]
 
 
+# ---------------------------------------------------------------- Keras model.summary() rows (name, type, output shape, params)
+# Restated from the graph-building code; pinned row by row against the summaries the reference's notebooks printed
+# (tests/golden/notebook_summaries.json, tests/test_oracle_pins.py).  Shapes are [None, H, W, C] with the batch as None.
+def _conv_params(kh, kw, cin, cout):
+    return kh * kw * cin * cout + cout
+
+
+def keras_summary_generator(scale=2, growth=32, num_rrdb=23, h=24, w=24, channels=3):
+    """ESRGAN_model.py:212-345 (layer names :230-341)."""
+    R = [["lr_input", "InputLayer", [None, h, w, channels], 0],
+         ["initial_conv", "Conv2D", [None, h, w, 64], _conv_params(3, 3, channels, 64)]]
+    for b in range(num_rrdb):
+        for d in (1, 2, 3):
+            n = f"rrdb_{b}_dense{d}"
+            for k in range(1, 5):
+                R.append([f"{n}_conv{k}", "Conv2D", [None, h, w, growth], _conv_params(3, 3, 64 + (k - 1) * growth, growth)])
+                R.append([f"{n}_concat{k}", "Concatenate", [None, h, w, 64 + k * growth], 0])
+            R.append([f"{n}_conv5", "Conv2D", [None, h, w, 64], _conv_params(3, 3, 64 + 4 * growth, 64)])
+            R += [[f"{n}_scale", "Lambda", [None, h, w, 64], 0], [f"{n}_add", "Add", [None, h, w, 64], 0]]
+        R += [[f"rrdb_{b}_scale", "Lambda", [None, h, w, 64], 0], [f"rrdb_{b}_add", "Add", [None, h, w, 64], 0]]
+    R += [["trunk_conv", "Conv2D", [None, h, w, 64], _conv_params(3, 3, 64, 64)], ["trunk_add", "Add", [None, h, w, 64], 0]]
+    sa = count_params(self_attention_layers("sa"))
+    R.append(["self_attention_trunk", "SelfAttention", [None, h, w, 64], sa])
+    for i in range(int(np.log2(scale))):
+        R.append([f"upsample_{i}_conv", "Conv2D", [None, h, w, 256], _conv_params(3, 3, 64, 256)])
+        h, w = 2 * h, 2 * w
+        R += [[f"upsample_{i}_pixelshuffle", "Lambda", [None, h, w, 64], 0], [f"upsample_{i}_leaky", "LeakyReLU", [None, h, w, 64], 0]]
+        if i == 0:
+            R.append(["self_attention_upsample_0", "SelfAttention", [None, h, w, 64], sa])
+    R += [["final_conv1", "Conv2D", [None, h, w, 64], _conv_params(3, 3, 64, 64)],
+          ["final_conv2", "Conv2D", [None, h, w, channels], _conv_params(3, 3, 64, channels)]]
+    return R
+
+
+def keras_summary_discriminator(h=48, w=48):
+    """ESRGAN_model.py:347-377: six SpectralNormalization(Conv2D 3x3 SAME) + LeakyReLU, strides 1,2,1,2,1,2; GAP; two
+    spectrally normalised Dense layers.  A wrapper's count = kernel + bias + its u vector [1, Cout]."""
+    R = [["hr_input", "InputLayer", [None, h, w, 3], 0]]
+    cin = 3
+    for i, (f, st) in enumerate([(64, 1), (64, 2), (64, 1), (128, 2), (128, 1), (256, 2)]):
+        h, w = -(-h // st), -(-w // st)                      # SAME: ceil(in / stride)
+        R.append(["spectral_normalization" + (f"_{i}" if i else ""), "SpectralNormalization", [None, h, w, f], _conv_params(3, 3, cin, f) + f])
+        R.append([f"disc_leaky{i + 1}", "LeakyReLU", [None, h, w, f], 0])
+        cin = f
+    R.append(["disc_gap", "GlobalAveragePooling2D", [None, 256], 0])
+    R.append(["spectral_normalization_6", "SpectralNormalization", [None, 256], 256 * 256 + 256 + 256])
+    R.append(["disc_leaky_dense1", "LeakyReLU", [None, 256], 0])
+    R.append(["spectral_normalization_7", "SpectralNormalization", [None, 1], 256 + 1 + 1])
+    return R
+
+
+def keras_summary_vgg(cfg, h, w, input_name, last=None):
+    """keras.applications VGG16/VGG19 without top: blockN_convK 3x3 SAME, blockN_pool 2x2 VALID (floor); `last` = name of the
+    last layer kept (ESRGAN_model.py:395 cuts VGG19 at block5_conv4)."""
+    R = [[input_name, "InputLayer", [None, h, w, 3], 0]]
+    cin = 3
+    for blk, n, f in cfg:
+        for k in range(1, n + 1):
+            R.append([f"block{blk}_conv{k}", "Conv2D", [None, h, w, f], _conv_params(3, 3, cin, f)])
+            cin = f
+            if last == R[-1][0]:
+                return R
+        h, w = h // 2, w // 2
+        R.append([f"block{blk}_pool", "MaxPooling2D", [None, h, w, f], 0])
+    return R
+
+
+def keras_summary_srcnn(h=24, w=24, channels=3):
+    """SRCNN_model.py:48-53."""
+    return [[n, "Conv2D", [None, h, w, s[-1]], _conv_params(*s)] for n, s in srcnn_layers(channels)]
+
+
+def keras_summary_edsr(scale=2, num_res_blocks=16, num_filters=64, channels=3):
+    """EDSR_model.py:55-125 with input_shape (None, None, 3): Keras auto-names in construction order."""
+    F = num_filters
+    sh = lambda c: [None, None, None, c]
+    R = [["input", "InputLayer", sh(channels), 0], ["conv2d", "Conv2D", sh(F), _conv_params(3, 3, channels, F)]]
+    ci, ai, li, di = 1, 0, 0, 0
+    suffix = lambda base, i: base if i == 0 else f"{base}_{i}"
+    for _ in range(num_res_blocks):
+        R.append([f"conv2d_{ci}", "Conv2D", sh(F), _conv_params(3, 3, F, F)]); ci += 1
+        R.append([suffix("activation", ai), "Activation", sh(F), 0]); ai += 1
+        R.append([f"conv2d_{ci}", "Conv2D", sh(F), _conv_params(3, 3, F, F)]); ci += 1
+        R.append([suffix("lambda", li), "Lambda", sh(F), 0]); li += 1
+        R.append([suffix("add", di), "Add", sh(F), 0]); di += 1
+    R.append([f"conv2d_{ci}", "Conv2D", sh(F), _conv_params(3, 3, F, F)]); ci += 1
+    R.append([suffix("add", di), "Add", sh(F), 0]); di += 1
+    for r in ([scale] if scale in (2, 3) else [2, 2]):
+        R.append([f"conv2d_{ci}", "Conv2D", sh(F * r * r), _conv_params(3, 3, F, F * r * r)]); ci += 1
+        R.append([suffix("lambda", li), "Lambda", sh(F), 0]); li += 1
+    R.append([f"conv2d_{ci}", "Conv2D", sh(channels), _conv_params(3, 3, F, channels)])
+    R.append(["clip_0_1", "Lambda", sh(channels), 0])
+    return R
+
+
+def keras_summary_vgg16_classifier(h=96, w=96, num_classes=2):
+    """VGG16_model.py:69-97: the nested functional `vgg16` is one row."""
+    base = keras_summary_vgg(VGG16_CFG, h, w, "input")
+    return [["input_2", "InputLayer", [None, h, w, 3], 0],
+            ["vgg16", "Functional", base[-1][2], sum(r[3] for r in base)],
+            ["gap", "GlobalAveragePooling2D", [None, 512], 0], ["dropout", "Dropout", [None, 512], 0],
+            ["dense", "Dense", [None, 256], 512 * 256 + 256], ["dropout_1", "Dropout", [None, 256], 0],
+            ["predictions", "Dense", [None, num_classes], 256 * num_classes + num_classes]]
+
+
 def count_params(layers):
     return int(sum(int(np.prod(s)) + s[-1] for _, s in layers))
 

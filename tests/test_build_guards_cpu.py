@@ -1,0 +1,55 @@
+"""Build-time guards that need no GPU: the assembly-level proof that the inline-asm prefetch loads of the 3x3 kernels are never
+touched before their explicit wait and that those kernels do not spill (tools/check_prefetch_hazards.py), and a
+self-test of the checker on a deliberately broken instruction stream."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _checker():
+    spec = importlib.util.spec_from_file_location("check_prefetch_hazards", os.path.join(ROOT, "tools", "check_prefetch_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_conv_rows_assembly_has_no_prefetch_hazard_and_no_spill():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch_hazards.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 problems" in r.stdout
+
+
+def test_checker_flags_a_register_touched_under_an_outstanding_load():
+    C = _checker()
+    bad = """
+_Zkernel_conv3_rows_kernel_bad:
+	global_load_dwordx4 v[4:7], v[0:1], off
+	global_load_dwordx4 v[8:11], v[0:1], off
+	s_waitcnt vmcnt(1)
+	v_mov_b32_e32 v12, v4
+	v_mov_b32_e32 v13, v9
+	s_waitcnt vmcnt(0)
+	v_mov_b32_e32 v14, v9
+	s_endpgm
+.Lfunc_end0:
+"""
+    k = C.parse_kernels(bad)
+    probs = C.check_kernel("bad", k["_Zkernel_conv3_rows_kernel_bad"])
+    assert len(probs) == 1 and "v13, v9" in probs[0]          # v4 landed (vmcnt(1)), v9 had not; after vmcnt(0) it is fine
+    loop = """
+_Zkernel_conv3_rows_kernel_loop:
+.LBB0_1:
+	s_waitcnt vmcnt(0)
+	ds_write_b128 v20, v[4:7]
+	global_load_dwordx4 v[4:7], v[0:1], off
+	s_cbranch_scc1 .LBB0_1
+	v_mov_b32_e32 v12, v4
+	s_endpgm
+.Lfunc_end0:
+"""
+    k = C.parse_kernels(loop)
+    probs = C.check_kernel("loop", k["_Zkernel_conv3_rows_kernel_loop"])
+    assert len(probs) == 1 and "v12, v4" in probs[0]          # the loop body is clean (wait first); the exit path is not
