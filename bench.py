@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--raw-glorot", action="store_true",
                     help="round 1's weights: glorot without conditioning the attention logits (sr355.weights.condition_attention)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--fused", type=int, default=3,
+                    help="dense-block conv pairs run as one fused kernel: bit 0 conv4+conv5, bit 1 conv2+conv3 (0 = layer by layer, for A/B runs)")
     args = ap.parse_args()
     if args.chunk <= 0:
         args.chunk = 441 * max(1, args.tiles_per_call)
@@ -152,6 +154,7 @@ def main():
     from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
 
     ctx = Context.get(local)
+    ctx.set_fused(args.fused, 0)
     models = []
     for _ in range(max(1, args.streams)):
         m_ = ESRGAN(compute_dtype="bf16")
@@ -263,7 +266,7 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: ESRGAN-RRDB x4 (NB=23,G=32,2xSelfAttention) on a batch of {global_tiles} LR tiles 512x512, "
                                    "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
                        "tiles_this_rank": n_mine, "global_batch": global_tiles, "patches_per_forward": min(args.chunk, 441 * max(n_mine, 1)),
-                       "tiles_per_call": args.tiles_per_call,
+                       "tiles_per_call": args.tiles_per_call, "fused_dense_pairs_mask": args.fused,
                        "parallelism": f"dp{world} (tile shards, metric all-reduce only)"},
             "quality": {"mean_psnr_vs_hr_db": res[0] / res[2], "mean_ssim_vs_hr": res[1] / res[2], "note": "random-init weights"},
             "whole_step": {"conv_tflop": CONV_TFLOP_PER_TILE * global_tiles, "conv_tflops_all_ranks": CONV_TFLOP_PER_TILE * global_tiles / (elapsed / args.steps),

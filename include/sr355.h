@@ -81,6 +81,14 @@ int  sr_measure_clock(sr_ctx* ctx, float* mhz, void* stream);
 /* Diagnostic only (never set in production): a device buffer of 16 uint64 per workgroup of the next 3x3 bf16 conv
  * launches; a separately compiled stamped variant of the kernel writes s_memtime stamps there (NULL switches back). */
 int  sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer);
+/* Diagnostic only: a device buffer of 64 x 4 x 64 x 4 uint64 for the stamped variant of the fused dense-block kernels (s_memtime at four
+ * points of each of the first 64 granules, waves 0, 5, 8, 11 of the first 64 workgroups; tools/probe_chain.py).  NULL switches back. */
+int  sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer);
+/* Which dense-block conv pairs of the ESRGAN trunk run as one fused line-buffer kernel when the shape allows (bf16, 32 growth
+ * channels, 48-pixel-wide images): bit 0 = conv4+conv5, bit 1 = conv2+conv3; default 3.  mask 0 = layer by layer (the A/B switch of
+ * the parity tests and of tools/ benchmarks).  max_workgroups > 0 caps the persistent grid (tests: several images per workgroup
+ * at small batches); 0 = one workgroup per CU. */
+int  sr_debug_set_fused(sr_ctx* ctx, int mask, int max_workgroups);
 /* Test hook: device allocations through this ctx fail (SR_ERR_OOM) once the bytes it holds would exceed `bytes`
  * (0 = no cap).  Lets the tests walk the out-of-memory path of sr_forward without filling a 288 GB card. */
 int  sr_debug_set_alloc_cap(sr_ctx* ctx, int64_t bytes);

@@ -94,10 +94,13 @@ struct Op {
     int conv = -1;
     int act = SR_ACT_LINEAR; float alpha = 1.f, beta1 = 0.f, beta2 = 0.f; int clip = 0, d2s = 1;
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
+    int chain = -1, chain_pos = 0;                  // conv: member (first / second) of m->chains[chain]
 };
 struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h)
 struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
 struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; };
+// two consecutive convs of a dense block that run as ONE kernel when the shape allows (dense_fused.hip): ops[first], ops[first + 1]
+struct ChainSpec { int conv_a = -1, conv_b = -1; int tail = 0; ChainWeights w; };
 
 }  // namespace
 
@@ -108,6 +111,7 @@ struct sr_model {
     int T = SR_DTYPE_BF16;
     std::vector<Param> params;
     std::vector<ConvSpec> convs;
+    std::vector<ChainSpec> chains;
     std::vector<BufSpec> bufs;
     std::vector<void*> bufp;
     std::vector<float*> dense_dev;    // per param index (dense kernels / biases on device), else nullptr
@@ -245,12 +249,25 @@ int build_esrgan(sr_model* m) {
         for (int d = 0; d < 3; ++d) {
             const std::string dn = "rrdb_" + std::to_string(r) + "_dense" + std::to_string(d + 1);
             const int I = cat[src[d]], O = cat[dst[d]];
+            const size_t first_op = m->ops.size();
             for (int k = 1; k <= 4; ++k)
                 b.conv(dn + "_conv" + std::to_string(k), 3, 64 + (k - 1) * G, G, {I, 0}, {I, 64 + (k - 1) * G}, SR_ACT_RELU);
             Op& o = b.conv(dn + "_conv5", 3, CC, 64, {I, 0}, {O, 0});
             if (d < 2) { o.alpha = 0.2f; o.skip1 = {I, 0}; o.beta1 = 1.f; }                 // x + 0.2*conv5 (ESRGAN_model.py:249-252)
             else { o.alpha = 0.04f; o.skip1 = {cat[X], 0}; o.beta1 = 1.f; o.skip2 = {I, 0}; o.beta2 = 0.2f; }
             // d == 2: rrdb_in + 0.2*(x + 0.2*conv5)  (ESRGAN_model.py:277-280)
+            if (m->bufs[I].blk && G == 32) {
+                // row-blocked buffers, 32 growth channels: conv2+conv3 and conv4+conv5 can each run as one line-buffered kernel on
+                // 48-pixel-wide images (dense_fused.hip); sr_forward decides per call and otherwise runs the ops one by one
+                auto link = [&](size_t opa, int tail) {
+                    ChainSpec cs; cs.conv_a = m->ops[opa].conv; cs.conv_b = m->ops[opa + 1].conv; cs.tail = tail;
+                    m->chains.push_back(cs);
+                    m->ops[opa].chain = m->ops[opa + 1].chain = (int)m->chains.size() - 1;
+                    m->ops[opa].chain_pos = 0; m->ops[opa + 1].chain_pos = 1;
+                };
+                link(first_op + 1, 0);
+                link(first_op + 3, 1);
+            }
         }
         const int nX = Y, nY = Z, nZ = X; X = nX; Y = nY; Z = nZ;
     }
@@ -407,6 +424,19 @@ int sr_measure_clock(sr_ctx* ctx, float* mhz, void* stream) {
     return clock_probe_launch(ctx, mhz, static_cast<hipStream_t>(stream));
 }
 
+int sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer) {
+    if (!ctx) return SR_ERR_INVALID;
+    ctx->chain_stamp_buf = static_cast<unsigned long long*>(device_u64_buffer);
+    return SR_OK;
+}
+
+int sr_debug_set_fused(sr_ctx* ctx, int mask, int max_workgroups) {
+    if (!ctx) return SR_ERR_INVALID;
+    ctx->chain_mask = mask;
+    ctx->chain_max_wgs = max_workgroups > 0 ? max_workgroups : 0;
+    return SR_OK;
+}
+
 int sr_debug_set_alloc_cap(sr_ctx* ctx, int64_t bytes) {
     if (!ctx) return SR_ERR_INVALID;
     ctx->alloc_cap = bytes > 0 ? bytes : 0;
@@ -482,6 +512,7 @@ void sr_model_destroy(sr_model* m) {
     (void)hipDeviceSynchronize();
     m->free_bufs();
     for (auto& c : m->convs) conv_free_weights(m->ctx, &c.w);
+    for (auto& ch : m->chains) chain_free_weights(m->ctx, &ch.w);
     for (auto& p : m->dense_dev) if (p) m->ctx->dfree(p);
     delete m;
 }
@@ -568,10 +599,9 @@ int sr_model_finalize(sr_model* m) {
     sr_ctx* ctx = m->ctx;
     for (auto& p : m->params)
         if (!p.set) return ctx->fail(SR_ERR_STATE, "parameter '" + p.name + (p.which ? "' bias" : "' kernel") + " was never set");
-    for (auto& c : m->convs) {
-        conv_free_weights(ctx, &c.w);
+    auto gather = [&](const ConvSpec& c, std::vector<float>& k, std::vector<float>& bias) {   // HWIO kernel + bias of a (possibly multi-part) conv
         const int taps = c.KS * c.KS;
-        std::vector<float> k((size_t)taps * c.Cin * c.Cout), bias(c.Cout);
+        k.assign((size_t)taps * c.Cin * c.Cout, 0.f); bias.assign(c.Cout, 0.f);
         int co0 = 0;
         for (auto& part : c.parts) {
             const Param& pk = m->params[m->find_param(part.name, SR_WEIGHT_KERNEL)];
@@ -583,7 +613,21 @@ int sr_model_finalize(sr_model* m) {
             for (int co = 0; co < part.cout; ++co) bias[co0 + co] = part.scale * pb.host[co];
             co0 += part.cout;
         }
+    };
+    for (auto& c : m->convs) {
+        conv_free_weights(ctx, &c.w);
+        std::vector<float> k, bias;
+        gather(c, k, bias);
         int rc = conv_pack_weights(ctx, k.data(), bias.data(), c.KS, c.Cin, c.Cout, m->T, &c.w);
+        if (rc) return rc;
+    }
+    for (auto& ch : m->chains) {
+        chain_free_weights(ctx, &ch.w);
+        const ConvSpec& a = m->convs[ch.conv_a], &bq = m->convs[ch.conv_b];
+        std::vector<float> ka, ba, kb, bb;
+        gather(a, ka, ba);
+        gather(bq, kb, bb);
+        int rc = chain_pack_weights(ctx, ka.data(), ba.data(), kb.data(), bb.data(), a.Cin / 32, a.Cout / 16, bq.Cout / 16, &ch.w);
         if (rc) return rc;
     }
     for (auto& op : m->ops) {
@@ -639,6 +683,28 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
             case OP_CONV: {
                 const ConvSpec& cs = m->convs[op.conv];
                 TensorView xin{m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, m->bufs[op.in.buf].blk};
+                if (op.chain >= 0) {
+                    const ChainSpec& ch = m->chains[op.chain];
+                    if ((ctx->chain_mask & (ch.tail ? 1 : 2)) && chain_supported(ch.w, xin, w)) {
+                        if (op.chain_pos == 0) {                  // the pair runs as one kernel, launched at its first op
+                            const Op& ob = m->ops[oi + 1];
+                            auto view = [&](const Ref& r) { return r.buf >= 0 ? TensorView{m->bufp[r.buf], m->bufs[r.buf].Cbuf, r.coff, m->bufs[r.buf].blk} : TensorView{}; };
+                            TensorView outv{}, so{};
+                            float bx = 0.f, bo = 0.f;
+                            if (ch.tail) {
+                                outv = view(ob.out);
+                                for (int k2 = 0; k2 < 2; ++k2) {   // which skip is the block's own input x, which the other tensor
+                                    const Ref& r = k2 ? ob.skip2 : ob.skip1;
+                                    const float be = k2 ? ob.beta2 : ob.beta1;
+                                    if (r.buf < 0) continue;
+                                    if (r.buf == op.in.buf && r.coff == 0) bx = be; else { so = view(r); bo = be; }
+                                }
+                            }
+                            rc = chain_launch(ctx, ch.w, xin, B, h, w, outv, so, ob.alpha, bx, bo, st);
+                        }
+                        break;
+                    }
+                }
                 ConvEpilogue ep;
                 ep.act = op.act; ep.alpha = op.alpha; ep.clip01 = op.clip; ep.d2s_r = op.d2s;
                 if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff, m->bufs[op.skip1.buf].blk}; ep.beta1 = op.beta1; }

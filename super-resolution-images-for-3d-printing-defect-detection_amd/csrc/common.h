@@ -29,6 +29,7 @@ struct sr_ctx {
     void* scratch_buf = nullptr;
     size_t scratch_cap = 0;
     unsigned long long* stamp_buf = nullptr;   // diagnostic: when set, conv3_rows runs its stamped variant
+    unsigned long long* chain_stamp_buf = nullptr;   // diagnostic: when set, the fused dense-block kernels run their stamped variant
 
     // per-launch HIP-event timing of the hot kernels (sr_profile_begin/_end)
     struct ProfRec { int name; hipEvent_t e0, e1; double flops, bytes; };
@@ -43,6 +44,10 @@ struct sr_ctx {
     // kernels whose dynamic-LDS ceiling has been raised on THIS context's device (hipFuncSetAttribute is per device)
     std::unordered_set<const void*> lds_attr_done;
     int ensure_dyn_lds(const void* kernel, int bytes);
+    void* zero_page = nullptr;    // 4 KiB of zeros (DMA source of padding rows in dense_fused.hip)
+    int num_cus = 0;
+    int chain_mask = 3;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3 (sr_debug_set_fused; default both)
+    int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
 
     void* dalloc(size_t bytes);   // nullptr on failure (err set)
@@ -117,6 +122,20 @@ void conv_free_weights(sr_ctx* ctx, ConvWeights* w);
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W,
                 void* y, int64_t y_cs, int y_coff, const ConvEpilogue& ep, hipStream_t st);
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W, TensorView y, const ConvEpilogue& ep, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// fused pair of dense-block convs (dense_fused.hip)
+// ---------------------------------------------------------------------------------------------
+struct ChainWeights {
+    void* w = nullptr; float* bias = nullptr;
+    int ext = 0, nb0 = 0, nb1 = 0;   // external 32-channel chunks both convs read; 16-cout blocks of the first / second conv
+    size_t bytes = 0;
+};
+int chain_pack_weights(sr_ctx* ctx, const float* wa_hwio, const float* ba, const float* wb_hwio, const float* bb, int ext, int nb0, int nb1, ChainWeights* out);
+void chain_free_weights(sr_ctx* ctx, ChainWeights* w);
+bool chain_supported(const ChainWeights& w, const TensorView& in, int W);
+int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H, int W, TensorView out, TensorView skip_o, float alpha, float beta_x,
+                 float beta_o, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // attention core: o = softmax(q k^T) v per image, tokens N=H*W.

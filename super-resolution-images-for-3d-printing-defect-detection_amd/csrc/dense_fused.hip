@@ -1,0 +1,592 @@
+// dense_fused.hip -- two consecutive 3x3 convs of an ESRGAN dense block (ESRGAN_model.py:212-254) in ONE persistent kernel.
+//
+// Why: layer by layer, a dense block moves ~2.3 KB per pixel through HBM (conv k re-reads every earlier feature) and the 3x3
+// kernel of conv_rows.hip is bound by that stream (1.0x algorithmic traffic at 4.3 TB/s).  Here conv_a's output
+// never leaves the CU before conv_b consumes it, and both convs share one staging of their common input chunks:
+//   conv4 + conv5 (the pair that owns 65 % of a block's FLOP): 160 + 32 + 192 + 64 channel reads/writes -> 160 + 64.
+//
+// Shape of the computation (W = 48 exactly: three 16-pixel column groups; any H; any batch):
+//   * a workgroup (8 waves, one per CU) owns a contiguous run of images and walks them top to bottom as ONE stream of rows,
+//     8 rows per step, with a zero separator row between images (it is the bottom padding of one image and the top padding
+//     of the next, so the MFMA loops never branch on image borders);
+//   * line-buffer skew: in step s the first conv (layer 0) produces stream rows [8s, 8s+8), the second (layer 1) rows
+//     [8s-1, 8s+7) -- layer 1's last input row is the row layer 0 finishes in the same step.  Layer 0's output lives in a
+//     10-row ring in LDS (rows [8s-2, 8s+8)); nothing is recomputed, every layer computes exactly 8 rows per step;
+//   * wave w owns row 8s+w of layer 0 and row 8s+w-1 of layer 1, all 48 columns, all output channels: the pixel fragment of
+//     an input row feeds both layers and all three ky taps it takes part in (0.56 LDS fragment reads per MFMA);
+//   * the external input (the dense block's concat buffer, row-blocked [B][H][C/32][W][32]: conv_common.h) is streamed one
+//     32-channel chunk at a time: 11 rows x 3 KiB per chunk land in one of two LDS buffers by LDS-DMA
+//     (global_load_lds_dwordx4, source-side XOR swizzle so that ds_read_b128 is conflict free) while the previous chunk
+//     multiplies; weights stream through a two-slot LDS ring in (chunk, kx) granules, host-packed in the order they are used;
+//   * one s_barrier per granule (54 MFMAs per wave): a granule's DMA is issued a whole granule ahead and retired with
+//     s_waitcnt vmcnt(0) just before the barrier that publishes it.
+// LDS: 2 x 33 KiB staging + 30 KiB ring + 2 x 18 KiB weights = 132 KiB -> one workgroup per CU, two waves per SIMD (the second
+// wave's MFMAs cover the first one's DMA issue and LDS latency).
+//
+// Epilogues: layer 0 = bias + ReLU -> bf16 -> LDS ring (+ global when a later kernel needs it); layer 1 = either the same
+// (growth conv) or the block's tail  alpha*(conv5 + b) + x [+ rrdb_in]  with x folded in from the staged chunk (the same
+// "skip from LDS" identity as conv_rows.hip) and written to channels [0,64) of the next block's buffer.
+#include <string.h>
+
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+struct ChainParams {
+    const char* in; int in_nch;        // source concat buffer (row-blocked bf16), 32-channel chunks per pixel
+    char* out; int out_nch;            // MODE 1: destination buffer of the block tail (channels [0, 64)); MODE 0: unused (outputs go into `in`)
+    const char* so; int so_nch;        // MODE 1: the other skip tensor (64 channels at chunk 0 of a row-blocked buffer) or nullptr
+    const char* w;                     // granule-ordered packed weights (pack_chain_weights)
+    const float* bias;                 // [16*NB0 | 16*NB1] fp32
+    const char* zero;                  // >= 1 KiB of zeros: DMA source of separator / out-of-stream rows
+    int B, H;
+    int imgs_per_wg; unsigned magic;   // g / (H+1) == umulhi(g, magic) for every stream row index that occurs
+    float alpha, xscale, beta_o;       // MODE 1: out = alpha * (acc + bias + xscale * x) + beta_o * so
+    unsigned long long* dbg;           // diagnostic builds only (sr_debug_set_chain_stamp_buffer): s_memtime stamps, [wg < 64][wave 0 / 5 / 8 / 11][granule < 64][4]
+};
+
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+constexpr int ROWB = 3072;             // one LDS / HBM row of a chunk: 48 pixels x 64 B
+constexpr int NSTG = 11;               // staged rows per chunk: stream rows [8s-2, 8s+9)
+constexpr int STGB = NSTG * ROWB;
+constexpr int WINR = 10;               // ring rows of layer 0's output: [8s-2, 8s+8)
+
+template <int NB0, int NB1> struct ChainLds {
+    static constexpr int WSLOT = (NB0 + NB1) * 3 * 1024;
+    static constexpr int NWS = 3;                                             // weight ring slots: the loaders run two granules ahead
+    static constexpr int BYTES = 2 * STGB + WINR * ROWB + NWS * WSLOT + (NB0 + NB1) * 16 * 4;
+};
+
+// lanes q and q^1 trade halves (v_permlane16_swap) so that every lane stores 8 consecutive channels (16 B): an even-q lane gets
+// channels 4q..4q+7 of block a, an odd-q lane channels 4(q-1)..4(q-1)+7 of block c  (same trick as conv_rows_epi.h)
+__device__ __forceinline__ void store_pair(const f32x4& a, const f32x4& c, char* dst) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 ab = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+    const bf16x4 cb = {(bf16_t)c[0], (bf16_t)c[1], (bf16_t)c[2], (bf16_t)c[3]};
+    const u32x2 au = __builtin_bit_cast(u32x2, ab), cu = __builtin_bit_cast(u32x2, cb);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
+    const u32x4 o = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+    *reinterpret_cast<u32x4*>(dst) = o;
+}
+
+// EXT: external 32-channel chunks both convs read; NB0 / NB1: 16-cout blocks of layer 0 / layer 1.
+// MODE 0: both layers are growth convs (ReLU) whose outputs go to chunks EXT and EXT+1 of the source buffer.
+// MODE 1: layer 0 is a growth conv kept on chip only, layer 1 is the block tail (NB1 = 4).
+#define CHAIN_STAMP(k) do { if (STAMP && blockIdx.x < 64 && G < 64 && (wave == 0 || wave == 5 || wave == 8 || wave == 11) && lane == 0)                \
+        p.dbg[(((size_t)blockIdx.x * 4 + (wave == 0 ? 0 : wave == 5 ? 1 : wave == 8 ? 2 : 3)) * 64 + G) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + loader waves (LDS-DMA issue only), one loader per SIMD
+
+// EXT: external 32-channel chunks both convs read; NB0 / NB1: 16-cout blocks of layer 0 / layer 1.
+// MODE 0: both layers are growth convs (ReLU) whose outputs go to chunks EXT and EXT+1 of the source buffer.
+// MODE 1: layer 0 is a growth conv kept on chip only, layer 1 is the block tail (NB1 = 4).
+//
+// Roles.  Issuing an LDS-DMA instruction holds the issuing wave for ~200-300 cycles here and all waves of a CU share one path from
+// L2 into LDS (in-kernel stamps, tools/probe_chain.py: ~40-50 cycles of that path per 1 KiB piece whoever issues it -- 4, 6 or 8
+// loader waves, or the compute waves themselves; s_setprio on the loaders changes nothing).  With every wave issuing its share
+// behind the barrier (first version) a granule spent 1.0-1.3 k cycles issuing and 1.7-2.1 k multiplying, one after the other.  So
+// the DMA stream belongs to four loader waves that do nothing else, running two granules ahead (three weight slots, counted
+// vmcnt): barrier -> issue -> wait for the previous iteration's pieces -> barrier; the eight compute waves go barrier -> MFMAs ->
+// barrier and touch vector memory only in the epilogues.  Measured and not kept: 6 / 8 loaders (same port time, compute waves
+// slower at 4 waves per SIMD and 128 registers), compute waves issuing 16 of a granule's 18 weight pieces (-10 %: everybody queues
+// on the port right after the barrier).  What bounds the kernel now is that path: 29-35 KiB per granule at ~20-25 B/clk is
+// 1.4-1.75 k cycles against 1.73 k cycles of MFMA per granule, and the two overlap only as far as three weight slots and two
+// staging buffers (all that fits beside the ring in 160 KiB) let the loaders run ahead.
+template <int EXT, int NB0, int NB1, int MODE, bool HAS_O, bool STAMP>
+__global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4) chain2_kernel(ChainParams p) {
+    using L = ChainLds<NB0, NB1>;
+    constexpr int NBT = NB0 + NB1, WSLOT = L::WSLOT;
+    constexpr int NGR = 3 * (EXT + 1);                 // granules per step: (chunk, kx) for the EXT external chunks + layer 0's own chunk
+    constexpr int EXTG = 3 * EXT;
+    constexpr int NTHR = (NCOMP + NLOAD) * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const stg = smem;
+    char* const win = smem + 2 * STGB;
+    char* const wr = win + WINR * ROWB;
+    constexpr int NWS = L::NWS;
+    float* const lbias = reinterpret_cast<float*>(wr + NWS * WSLOT);
+
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, Hp1 = H + 1;
+    const int img0 = blockIdx.x * p.imgs_per_wg;
+    const int nimg = min(p.imgs_per_wg, p.B - img0);
+    if (nimg <= 0) return;                             // whole workgroup (uniform)
+    const int N = nimg * Hp1;                          // stream rows, separators included
+    const int nsteps = (N + 1 + 7) >> 3;               // layer 1 lags one row
+
+    // ---- one-time LDS state: the ring starts as zeros (rows above the first image), biases parked for the epilogues
+    for (int u = tid; u < WINR * ROWB / 16; u += NTHR) *reinterpret_cast<f32x4*>(win + u * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < NBT * 16) lbias[tid] = p.bias[tid];
+
+    auto row_of = [&](int g, int& img, int& y) -> bool {          // stream row -> (image, row); false: separator / outside the stream
+        if (g < 0 || g >= N) return false;
+        img = (int)__umulhi((unsigned)g, p.magic);
+        y = g - img * Hp1;
+        return y < H;
+    };
+    int G = 0;
+    auto dma = [&](const char* src, char* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    // Weight pieces of the granule with running number Gw at position iw of its step: pieces [0, WCOMP) are issued by the compute
+    // waves (two each at most -- a piece costs the issuing wave ~230 cycles, which its SIMD partner covers with MFMAs), the rest by the
+    // loaders; `first`, `stride`: this wave's share.  Returns the number issued.
+    constexpr int WCOMP = 0;                   // all pieces belong to the loaders (see "Roles" above)
+    auto weights_of = [&](int Gw, int iw, bool live, int first, int stride, int lo, int hi) -> int {
+        if (!live) return 0;
+        const bool ext = iw < EXTG;
+        const int nw = min(ext ? NBT * 3 : NB1 * 3, hi);
+        const char* wsrc = p.w + (ext ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024));
+        char* wdst = wr + (Gw % NWS) * WSLOT;
+        int n = 0;
+        for (int k = lo + first; k < nw; k += stride, ++n) dma(wsrc + k * 1024 + lane * 16, wdst + k * 1024);
+        return n;
+    };
+    auto next_pos = [&](int& s_, int& i_) { if (++i_ == NGR) { i_ = 0; ++s_; } };
+    auto wait_all_but = [&](int n) {          // s_waitcnt vmcnt(n): everything but this wave's n youngest vector-memory operations has completed
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than the table covers: wait for everything (slower, never wrong)
+        }
+    };
+
+    if (wave >= NCOMP) {
+        // =========================================================================================== loader waves
+        const int lw = wave - NCOMP;
+        // LDS-DMA source swizzle: lane i of a 1 KiB piece fills LDS slot i -> pixel i/4, slice position i%4, which must hold global slice
+        // (i%4) ^ 2*bit2(pixel)
+        const int lsrc = 64 * (lane >> 2) + 16 * ((lane & 3) ^ (2 * ((lane >> 4) & 1)));
+        auto stage_piece = [&](int s2, int c1, int pid, char* sdst) {   // piece pid (row j, 16-pixel third pc) of chunk c1 of step s2
+            const int j = pid / 3, pc = pid - 3 * j;
+            int img, y;
+            const bool real = row_of(8 * s2 - 2 + j, img, y);
+            const char* src = real ? p.in + (((int64_t)(img0 + img) * H + y) * p.in_nch + c1) * ROWB + pc * 1024 + lsrc : p.zero + lane * 16;
+            dma(src, sdst + j * ROWB + pc * 1024);
+        };
+        // Schedule.  In the iteration of granule g (after the barrier that opens g) a loader issues
+        //   * the weights of granule g+2 into ring slot (g+2) % 3 (last read in granule g-1), and
+        //   * in the first two granules of an external chunk n, half of chunk n+1's 33 row pieces into staging buffer (n+1) & 1
+        //     (last read in chunk n-1),
+        // then waits, with a COUNTED vmcnt, for what it issued in the PREVIOUS iteration (vmcnt retires in order) and meets the
+        // barrier that opens granule g+1 -- which therefore publishes granule g+1's weights and, after the second granule of chunk n,
+        // all of chunk n+1.  Every piece has a full granule of MFMA time to land; the loaders' own limit is the CU's vector-memory
+        // issue port (~40-50 cycles per 1 KiB piece, in-kernel stamps).
+        // prologue: weights of granules 0 and 1, external chunk 0 of step 0; all of it is waited for before the first barrier
+        weights_of(0, 0, true, lw, NLOAD, 0, 1 << 20);
+        weights_of(1, 1, true, lw, NLOAD, 0, 1 << 20);
+        for (int k = lw; k < 33; k += NLOAD) stage_piece(0, 0, k, stg);
+        int nch = 0;
+        int s2w = 0, i2w = 1;                                            // position of granule G+1; advanced to G+2 before use
+        for (int s = 0; s < nsteps; ++s) {
+            for (int i = 0; i < NGR; ++i, ++G) {
+                CHAIN_STAMP(0);
+                // retire the previous iteration's pieces (all but the ones this iteration will issue are older) -- first iteration: everything
+                if (G == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                CHAIN_STAMP(1);
+                next_pos(s2w, i2w);                                      // -> granule G+2
+                int nissued = weights_of(G + 2, i2w, s2w < nsteps, lw, NLOAD, WCOMP, 1 << 20);   // the pieces the compute waves leave
+                if (i < EXTG) {
+                    const int c = i / 3, kx = i - 3 * c;
+                    if (kx < 2) {
+                        int c1 = c + 1, s2 = s;
+                        if (c1 == EXT) { c1 = 0; s2 = s + 1; }
+                        if (s2 < nsteps) {
+                            char* sdst = stg + ((nch + 1) & 1) * STGB;
+                            const int base = kx == 0 ? 0 : 17, cnt = kx == 0 ? 17 : 16;
+                            for (int k = lw; k < cnt; k += NLOAD, ++nissued) stage_piece(s2, c1, base + k, sdst);
+                        }
+                    } else {
+                        ++nch;
+                    }
+                }
+                CHAIN_STAMP(2);
+                // wait for the PREVIOUS iteration's pieces: all but this iteration's `nissued` youngest (vmcnt retires in order)
+                wait_all_but(nissued);
+                CHAIN_STAMP(3);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // =============================================================================================== compute waves
+    // pixel fragment (B operand) of column group cg, tap kx at a row whose LDS base is R:  R + 1024*cg + offk[kx]
+    //   column c = 16*cg + px + kx - 1, 64 B per pixel, 16-byte slice q at (q ^ 2*bit2(c)) -- conflict free for ds_read_b128
+    int offk[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int c = px + kx - 1;
+        offk[kx] = 64 * c + 16 * (q ^ (2 * ((c >> 2) & 1)));
+    }
+    const bool edge_l = px == 0, edge_r = px == 15;    // column -1 (kx 0, cg 0) and column 48 (kx 2, cg 2) are padding: fragment forced to zero
+    const int off_l = edge_l ? offk[1] : offk[0];      // ... and read from a valid address
+    const int off_r = edge_r ? offk[1] : offk[2];
+
+    f32x4 a0[NB0][3], a1[NB1][3];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // Row-major walk of a granule: the three column-group fragments of one input row are read once and meet every weight fragment that
+    // row pairs with (both layers, one ky each) before the next row is touched -- 12 + 6 x 4 registers of operands live at a time.
+    // one (chunk, kx) granule on an external chunk staged at `sb`: staged row j holds stream row 8s-2+j; layer 0 (row 8s+w) reads
+    // j = w+1+ky, layer 1 (row 8s+w-1) reads j = w+ky
+    auto ext_granule = [&](auto KXc, const char* sb, const char* ws) {
+        constexpr int KX = decltype(KXc)::value;
+        const char* rb = sb + wave * ROWB;
+        auto load_row = [&](int d, bf16x8 (&x)[3]) {
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) {
+                const int off = (KX == 0 && cg == 0) ? off_l : (KX == 2 && cg == 2) ? off_r : offk[KX];
+                x[cg] = *reinterpret_cast<const bf16x8*>(rb + d * ROWB + cg * 1024 + off);
+                if ((KX == 0 && cg == 0 && edge_l) || (KX == 2 && cg == 2 && edge_r)) x[cg] = bf16x8{};
+            }
+        };
+        bf16x8 xc[3], xn[3];
+        load_row(0, xc);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (d < 3) load_row(d + 1, xn);                  // next row's fragments fly under this row's MFMAs
+            if (d >= 1) {
+#pragma unroll
+                for (int n = 0; n < NB0; ++n) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + ((d - 1) * NB0 + n) * 1024 + lane * 16);
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) a0[n][cg] = mma16(wf, xc[cg], a0[n][cg]);
+                }
+            }
+            if (d <= 2) {
+#pragma unroll
+                for (int n = 0; n < NB1; ++n) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + (3 * NB0 + d * NB1 + n) * 1024 + lane * 16);
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) a1[n][cg] = mma16(wf, xc[cg], a1[n][cg]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);               // keep the scheduler from hoisting the whole granule's operand reads (168-register budget)
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) xc[cg] = xn[cg];
+        }
+    };
+    // one kx granule of layer 1 on layer 0's output: ring rows r1-1, r1, r1+1 with r1 = 8s+w-1
+    auto ring_granule = [&](auto KXc, int s, const char* ws) {
+        constexpr int KX = decltype(KXc)::value;
+        auto load_row = [&](int ky, bf16x8 (&x)[3]) {
+            const char* rb = win + ((8 * s + wave - 2 + ky + 2 * WINR) % WINR) * ROWB;
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) {
+                const int off = (KX == 0 && cg == 0) ? off_l : (KX == 2 && cg == 2) ? off_r : offk[KX];
+                x[cg] = *reinterpret_cast<const bf16x8*>(rb + cg * 1024 + off);
+                if ((KX == 0 && cg == 0 && edge_l) || (KX == 2 && cg == 2 && edge_r)) x[cg] = bf16x8{};
+            }
+        };
+        bf16x8 xc[3], xn[3];
+        load_row(0, xc);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if (ky < 2) load_row(ky + 1, xn);
+#pragma unroll
+            for (int n = 0; n < NB1; ++n) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + (ky * NB1 + n) * 1024 + lane * 16);
+#pragma unroll
+                for (int cg = 0; cg < 3; ++cg) a1[n][cg] = mma16(wf, xc[cg], a1[n][cg]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) xc[cg] = xn[cg];
+        }
+    };
+    // Granule boundary of a compute wave: its LDS reads / writes of the finished granule are done, the weight pieces it issued one
+    // granule ago have landed (counted wait: the ones it issued in the granule just finished stay in flight); then the barrier that
+    // publishes everybody's pieces; then its share of the weights two granules ahead.
+    int s2w = 0, i2w = 1, mine = 0;
+    auto sync = [&]() {
+        wait_all_but(mine);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        next_pos(s2w, i2w);
+        mine = weights_of(G + 2, i2w, s2w < nsteps, wave, NCOMP, 0, WCOMP);
+    };
+
+    int nch = 0;
+    for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int n = 0; n < NB0; ++n)
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) a0[n][cg] = zero4;
+#pragma unroll
+        for (int n = 0; n < NB1; ++n)
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) a1[n][cg] = zero4;
+
+#pragma nounroll
+        for (int c = 0; c < EXT; ++c, ++nch) {
+            const char* sb = stg + (nch & 1) * STGB;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx, ++G) {
+                CHAIN_STAMP(0);
+                sync();
+                CHAIN_STAMP(1);
+                CHAIN_STAMP(2);
+                const char* ws = wr + (G % NWS) * WSLOT;
+                if (kx == 0) ext_granule(std::integral_constant<int, 0>{}, sb, ws);
+                else if (kx == 1) ext_granule(std::integral_constant<int, 1>{}, sb, ws);
+                else ext_granule(std::integral_constant<int, 2>{}, sb, ws);
+                CHAIN_STAMP(3);
+            }
+            if (MODE == 1 && c < 2) {
+                // the block's own input x (channels [0,64) = chunks 0,1) is layer 1's skip: fold xscale * x(centre pixel) into the accumulators
+                // of cout blocks 2c, 2c+1 from the staged image (row j = w+1)
+                const float sc = p.xscale;
+#pragma unroll
+                for (int cg = 0; cg < 3; ++cg)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int slice = h * 2 + (q >> 1);
+                        const bf16x4 xk = *reinterpret_cast<const bf16x4*>(sb + (wave + 1) * ROWB + cg * 1024 + 64 * px + 16 * (slice ^ (2 * ((px >> 2) & 1))) + (q & 1) * 8);
+                        if (c == 0) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a1[h][cg][e] += sc * (float)xk[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a1[2 + h][cg][e] += sc * (float)xk[e];
+                        }
+                    }
+            }
+        }
+        // ---- layer 0 epilogue: bias + ReLU -> bf16 -> ring row (8s+w) mod 10 (zeros on separator / out-of-stream rows)
+        {
+            const int g0 = 8 * s + wave;
+            int img, y;
+            const bool real = row_of(g0, img, y);
+            char* wrow = win + (g0 % WINR) * ROWB;
+            char* grow = real && MODE == 0 ? const_cast<char*>(p.in) + (((int64_t)(img0 + img) * H + y) * p.in_nch + EXT) * ROWB : nullptr;
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) {
+                f32x4 v[NB0];
+#pragma unroll
+                for (int n = 0; n < NB0; ++n) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[n][e] = real ? fmaxf(a0[n][cg][e] + b[e], 0.f) : 0.f;
+                    const bf16x4 o = {(bf16_t)v[n][0], (bf16_t)v[n][1], (bf16_t)v[n][2], (bf16_t)v[n][3]};
+                    const int slice = n * 2 + (q >> 1);
+                    *reinterpret_cast<bf16x4*>(wrow + cg * 1024 + 64 * px + 16 * (slice ^ (2 * ((px >> 2) & 1))) + (q & 1) * 8) = o;
+                }
+                if (MODE == 0 && grow) {
+                    static_assert(MODE == 1 || NB0 == 2, "growth convs have 32 output channels");
+                    store_pair(v[0], v[NB0 - 1], grow + (16 * cg + px) * 64 + ((q & 1) * 16 + 4 * (q & ~1)) * 2);
+                }
+            }
+        }
+        // ---- layer 1 on layer 0's output
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx, ++G) {
+            CHAIN_STAMP(0);
+            sync();
+            CHAIN_STAMP(1);
+            CHAIN_STAMP(2);
+            const char* ws = wr + (G % NWS) * WSLOT;
+            if (kx == 0) ring_granule(std::integral_constant<int, 0>{}, s, ws);
+            else if (kx == 1) ring_granule(std::integral_constant<int, 1>{}, s, ws);
+            else ring_granule(std::integral_constant<int, 2>{}, s, ws);
+            CHAIN_STAMP(3);
+        }
+        // ---- layer 1 epilogue (row 8s+w-1)
+        {
+            int img, y;
+            const bool real = row_of(8 * s + wave - 1, img, y);
+            if (real) {
+                const int64_t rowi = (int64_t)(img0 + img) * H + y;
+                const int lane_c = (q & 1) * 16 + 4 * (q & ~1);
+                if (MODE == 0) {
+                    char* grow = const_cast<char*>(p.in) + (rowi * p.in_nch + EXT + 1) * ROWB;
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) {
+                        f32x4 v[2];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + (NB0 + n) * 16 + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[n][e] = fmaxf(a1[n][cg][e] + b[e], 0.f);
+                        }
+                        store_pair(v[0], v[1], grow + (16 * cg + px) * 64 + lane_c * 2);
+                    }
+                } else {
+                    const float alpha = p.alpha, beta_o = p.beta_o;
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) {
+                        bf16x4 ko[NB1];
+                        if (HAS_O) {
+                            const char* srow = p.so + rowi * p.so_nch * ROWB;
+#pragma unroll
+                            for (int n = 0; n < NB1; ++n)
+                                ko[n] = *reinterpret_cast<const bf16x4*>(srow + (n >> 1) * ROWB + (16 * cg + px) * 64 + ((n & 1) * 16 + 4 * q) * 2);
+                        }
+                        f32x4 v[NB1];
+#pragma unroll
+                        for (int n = 0; n < NB1; ++n) {
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + (NB0 + n) * 16 + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[n][e] = alpha * (a1[n][cg][e] + b[e]);
+                                if (HAS_O) v[n][e] += beta_o * (float)ko[n][e];
+                            }
+                        }
+#pragma unroll
+                        for (int h = 0; h < NB1 / 2; ++h)
+                            store_pair(v[2 * h], v[2 * h + 1], p.out + (rowi * p.out_nch + h) * ROWB + (16 * cg + px) * 64 + lane_c * 2);
+                    }
+                }
+            }
+        }
+    }
+}
+
+uint16_t bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <int EXT, int NB0, int NB1, int MODE>
+int launch_chain(sr_ctx* ctx, const ChainParams& p, bool has_o, int nwg, hipStream_t st) {
+    constexpr int lds = ChainLds<NB0, NB1>::BYTES;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (p.dbg) {                                  // diagnostic stamped variant (never in production)
+        auto k = chain2_kernel<EXT, NB0, NB1, MODE, MODE == 1, true>;
+        if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), lds)) return rc;
+        ChainParams q = p;
+        if (MODE == 1 && !has_o) { q.so = p.in; q.so_nch = p.in_nch; q.beta_o = 0.f; }   // the stamped build always carries the skip loads
+        hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), lds, st, q);
+    } else if (has_o) {
+        auto k = chain2_kernel<EXT, NB0, NB1, MODE, true, false>;
+        if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), lds, st, p);
+    } else {
+        auto k = chain2_kernel<EXT, NB0, NB1, MODE, false, false>;
+        if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), lds, st, p);
+    }
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weights of the pair (conv_a: Cin_a = 32*ext -> 16*nb0 couts, conv_b: Cin_b = 32*(ext+1) -> 16*nb1 couts), HWIO fp32, packed in
+// the order the kernel consumes them: for each external chunk c and kx: [a: ky x cout block][b: ky x cout block] (1 KiB MFMA
+// A-fragments, lane l element j = W[ky][kx][32c + 8(l>>4) + j][16 blk + (l&15)]), then for conv_b's last chunk (= conv_a's
+// output) and kx: [b: ky x cout block].
+int chain_pack_weights(sr_ctx* ctx, const float* wa, const float* ba, const float* wb, const float* bb, int ext, int nb0, int nb1, ChainWeights* out) {
+    const int cin_a = 32 * ext, cin_b = 32 * (ext + 1), cout_a = 16 * nb0, cout_b = 16 * nb1;
+    const size_t nfrag = (size_t)3 * ext * 3 * (nb0 + nb1) + (size_t)3 * 3 * nb1;
+    std::vector<uint16_t> host(nfrag * 512);
+    size_t idx = 0;
+    auto frag = [&](const float* w, int cin, int cout, int c, int ky, int kx, int blk) {
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j)
+                host[idx++] = bf16_host(w[((size_t)(ky * 3 + kx) * cin + 32 * c + 8 * (l >> 4) + j) * cout + 16 * blk + (l & 15)]);
+    };
+    for (int c = 0; c < ext; ++c)
+        for (int kx = 0; kx < 3; ++kx) {
+            for (int ky = 0; ky < 3; ++ky) for (int n = 0; n < nb0; ++n) frag(wa, cin_a, cout_a, c, ky, kx, n);
+            for (int ky = 0; ky < 3; ++ky) for (int n = 0; n < nb1; ++n) frag(wb, cin_b, cout_b, c, ky, kx, n);
+        }
+    for (int kx = 0; kx < 3; ++kx)
+        for (int ky = 0; ky < 3; ++ky) for (int n = 0; n < nb1; ++n) frag(wb, cin_b, cout_b, ext, ky, kx, n);
+    ChainWeights cw;
+    cw.ext = ext; cw.nb0 = nb0; cw.nb1 = nb1;
+    cw.bytes = host.size() * 2;
+    cw.w = ctx->dalloc(cw.bytes);
+    if (!cw.w) return SR_ERR_OOM;
+    cw.bias = static_cast<float*>(ctx->dalloc(sizeof(float) * (cout_a + cout_b)));
+    if (!cw.bias) { ctx->dfree(cw.w); return SR_ERR_OOM; }
+    std::vector<float> hb(cout_a + cout_b, 0.f);
+    if (ba) for (int i = 0; i < cout_a; ++i) hb[i] = ba[i];
+    if (bb) for (int i = 0; i < cout_b; ++i) hb[cout_a + i] = bb[i];
+    SR_HIP(ctx, hipMemcpy(cw.w, host.data(), cw.bytes, hipMemcpyHostToDevice));
+    SR_HIP(ctx, hipMemcpy(cw.bias, hb.data(), sizeof(float) * hb.size(), hipMemcpyHostToDevice));
+    *out = cw;
+    return SR_OK;
+}
+
+void chain_free_weights(sr_ctx* ctx, ChainWeights* w) {
+    if (w->w) ctx->dfree(w->w);
+    if (w->bias) ctx->dfree(w->bias);
+    w->w = nullptr; w->bias = nullptr;
+}
+
+bool chain_supported(const ChainWeights& w, const TensorView& in, int W) {
+    return w.w != nullptr && W == 48 && in.blk && in.coff == 0 && in.cs % 32 == 0 && in.cs >= 32 * (w.ext + (w.nb1 == 4 ? 1 : 2));
+}
+
+// in: the dense block's row-blocked concat buffer.  tail (nb1 == 4): out = alpha*(conv_b + bias) + beta_x * x + beta_o * skip_o into channels
+// [0,64) of `out` (x = channels [0,64) of `in`).  Otherwise both convs are growth convs writing chunks ext and ext+1 of `in`.
+int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H, int W, TensorView out, TensorView skip_o, float alpha,
+                 float beta_x, float beta_o, hipStream_t st) {
+    if (!chain_supported(w, in, W)) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: needs W == 48 and a row-blocked source buffer");
+    if (B <= 0 || H <= 0) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: empty tensor");
+    const bool tail = w.nb1 == 4;
+    if (tail && (!out.p || !out.blk || out.coff != 0 || out.cs % 32 != 0 || alpha == 0.f)) return ctx->fail(SR_ERR_INVALID, "fused dense-block tail: bad destination view");
+    if (skip_o.p && (!skip_o.blk || skip_o.coff != 0 || skip_o.cs % 32 != 0)) return ctx->fail(SR_ERR_INVALID, "fused dense-block tail: bad skip view");
+    if (!ctx->zero_page) {
+        ctx->zero_page = ctx->dalloc(4096);
+        if (!ctx->zero_page) return SR_ERR_OOM;
+        SR_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, 4096, st));
+    }
+    int ncu = ctx->num_cus;
+    if (ncu <= 0) {
+        hipDeviceProp_t prop;
+        SR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ncu = ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if (ctx->chain_max_wgs > 0 && ctx->chain_max_wgs < ncu) ncu = ctx->chain_max_wgs;      // test hook: several images per workgroup at small batches
+    ChainParams p;
+    p.in = static_cast<const char*>(in.p); p.in_nch = (int)(in.cs / 32);
+    p.out = static_cast<char*>(const_cast<void*>(out.p)); p.out_nch = (int)(out.cs / 32);
+    p.so = static_cast<const char*>(skip_o.p); p.so_nch = (int)(skip_o.cs / 32);
+    p.w = static_cast<const char*>(w.w); p.bias = w.bias; p.zero = static_cast<const char*>(ctx->zero_page);
+    p.B = B; p.H = H;
+    p.imgs_per_wg = (B + ncu - 1) / ncu;
+    const int nwg = (B + p.imgs_per_wg - 1) / p.imgs_per_wg;
+    p.magic = (unsigned)(((1ull << 32) + (unsigned)H) / (unsigned)(H + 1));                 // ceil(2^32 / (H+1)): exact quotient for g < 2^32 / (H+1)
+    if ((int64_t)p.imgs_per_wg * (H + 1) + 16 >= (1ll << 20)) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: stream too long");
+    p.alpha = alpha; p.xscale = tail ? beta_x / alpha : 0.f; p.beta_o = beta_o;
+    p.dbg = ctx->chain_stamp_buf;
+    int rec = -1;
+    if (ctx->prof) {
+        const double px = (double)B * H * W;
+        const double cin_a = 32.0 * w.ext, cin_b = 32.0 * (w.ext + 1), ca = 16.0 * w.nb0, cb = 16.0 * w.nb1;
+        // algorithmic bytes: the shared input once, what leaves the chip, the skips
+        double bytes = px * 2.0 * (cin_a + (tail ? cb : ca + cb));   // the shared input once + what leaves the chip (the tail's x skip is part of the input)
+        if (tail && skip_o.p) bytes += px * 2.0 * 64.0;
+        rec = ctx->prof_open(tail ? "dense_tail_fused<bf16,conv4+conv5>" : "dense_pair_fused<bf16>", 2.0 * px * 9.0 * (cin_a * ca + cin_b * cb), bytes, st);
+    }
+    int rc;
+    const bool has_o = skip_o.p != nullptr;
+    if (tail && w.ext == 5 && w.nb0 == 2) rc = launch_chain<5, 2, 4, 1>(ctx, p, has_o, nwg, st);
+    else if (!tail && w.ext == 2 && w.nb0 == 2 && w.nb1 == 2) rc = launch_chain<2, 2, 2, 0>(ctx, p, false, nwg, st);
+    else if (!tail && w.ext == 3 && w.nb0 == 2 && w.nb1 == 2) rc = launch_chain<3, 2, 2, 0>(ctx, p, false, nwg, st);
+    else rc = ctx->fail(SR_ERR_INVALID, "fused dense-block pair: shape not instantiated");
+    ctx->prof_close(rec, st);
+    return rc;
+}

@@ -36,6 +36,8 @@ SIGNATURES = {
     "sr_last_forward_ms": (_i, [_vp, _fp]),
     "sr_debug_set_stamp_buffer": (_i, [_vp, _vp]),
     "sr_measure_clock": (_i, [_vp, _fp, _vp]),
+    "sr_debug_set_chain_stamp_buffer": (_i, [_vp, _vp]),
+    "sr_debug_set_fused": (_i, [_vp, _i, _i]),
     "sr_debug_set_alloc_cap": (_i, [_vp, _i64]),
     "sr_profile_begin": (_i, [_vp]),
     "sr_profile_end": (_i, [_vp, C.c_char_p, _i64]),

@@ -113,6 +113,10 @@ class Context:
         self.check(self.lib.sr_measure_clock(self.h, C.byref(mhz), self.stream()))
         return mhz.value
 
+    def set_fused(self, mask=3, max_workgroups=0):
+        """Which dense-block conv pairs run as one fused kernel (bit 0: conv4+conv5, bit 1: conv2+conv3); 0 = layer by layer."""
+        self.check(self.lib.sr_debug_set_fused(self.h, int(mask), int(max_workgroups)))
+
     def set_alloc_cap(self, nbytes):
         """Test hook: allocations through this context fail once it would hold more than nbytes (0 = no cap)."""
         self.check(self.lib.sr_debug_set_alloc_cap(self.h, int(nbytes)))

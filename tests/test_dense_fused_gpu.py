@@ -1,0 +1,108 @@
+"""The fused dense-block kernels (csrc/dense_fused.hip: conv2+conv3 and conv4+conv5 of an ESRGAN dense block as one line-buffered
+persistent kernel each, ESRGAN_model.py:212-254) against the layer-by-layer path and against the CPU oracle in its bf16-storage
+mode.  The fused path needs 48-pixel-wide images and row-blocked buffers (bf16, G = 32); everything else about the shape is free:
+any height (the rows of a workgroup's images form one stream with zero separator rows), any batch (several images per
+workgroup when the batch exceeds the grid -- forced here with a small grid cap)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as M
+from oracle import ops as O
+from sr355 import Model
+from sr355.weights import bf16_rounded, init_weights, round_to_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture()
+def fused_ctx(ctx):
+    yield ctx
+    ctx.set_fused(3, 0)
+
+
+CASES = [
+    # B, H, grid cap (0 = one workgroup per CU)
+    (3, 48, 0),      # the bench shape, one image per workgroup
+    (7, 48, 2),      # 4 + 3 images per workgroup: separator rows between images, uneven split
+    (5, 9, 2),       # height not a multiple of the 8-row step
+    (4, 1, 3),       # one-row images: every second stream row is a separator
+    (2, 17, 0),
+    (9, 8, 4),       # height == step
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mask", [1, 2, 3])
+def test_fused_pairs_match_layer_by_layer_and_oracle(fused_ctx, case, mask):
+    ctx = fused_ctx
+    B, H, cap = case
+    nb = 2                                                                    # dense3's tail carries the second skip (rrdb input)
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, num_blocks=nb, growth_channels=32, use_attention=False, ctx=ctx)
+    w = bf16_rounded(init_weights(m.layer_shapes(), seed=3400))
+    m.set_weights(w)
+    x = round_to_bf16(np.random.default_rng(B * 100 + H).uniform(-1, 1, (B, H, 48, 3)).astype(np.float32))
+    xd = ctx.to_device(x, torch.bfloat16)
+    names = [f"rrdb_{b}_dense{d}_conv5" for b in range(nb) for d in (1, 2, 3)] + ["rrdb_0_dense1_conv3", "rrdb_1_dense2_conv2"]
+    ctx.set_fused(0, 0)
+    y0, t0 = m.forward_with_taps(xd, names)
+    ctx.set_fused(mask, cap)
+    y1, t1 = m.forward_with_taps(xd, names)
+    y1b = m.forward(xd)
+    assert torch.equal(y1, y1b)                                               # re-run on the same workspaces: same image
+    parts = {}
+    ref = M.esrgan_g_forward(x, w, 2, nb, dtype=np.float64, attention=False, bf16_storage=True, parts=parts)
+    # stage by stage: the fused path is as close to the oracle as the layer-by-layer path is (same roundings, other summation order)
+    for n in names:
+        a, b = t0[n].cpu().numpy(), t1[n].cpu().numpy()
+        assert rel_l2(b, a) <= 4e-3, (n, rel_l2(b, a))
+    for bi in range(nb):
+        got = t1[f"rrdb_{bi}_dense3_conv5"].cpu().numpy()
+        assert rel_l2(got, parts[f"rrdb_{bi}"]) <= 4e-3, (bi, rel_l2(got, parts[f"rrdb_{bi}"]))
+    e0, e1 = rel_l2(y0.float().cpu().numpy(), ref), rel_l2(y1.float().cpu().numpy(), ref)
+    assert e1 <= 5e-3 and e1 <= 2.0 * e0 + 1e-3, (e0, e1)
+
+
+def test_fused_tail_exact_integers(fused_ctx):
+    """Exact check of the index arithmetic (fragment packing order, ring rows, separator rows, channel offsets of the stores, the
+    folded skip): small-integer weights and inputs make every partial sum exact in bf16/fp32, so fused and layer-by-layer outputs
+    must be IDENTICAL and equal to the oracle, not just close."""
+    ctx = fused_ctx
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, num_blocks=1, growth_channels=32, use_attention=False, ctx=ctx)
+    rng = np.random.default_rng(7)
+    w = {}
+    for name, shape in m.layer_shapes():
+        k = np.zeros(shape, np.float32)
+        if "dense" in name:                                                   # sparse small integers: sums stay far below 2^8
+            nz = rng.random(shape) < 0.02
+            k[nz] = rng.integers(-2, 3, size=int(nz.sum()))
+            b = rng.integers(-1, 2, size=shape[-1]).astype(np.float32)
+        elif name == "initial_conv":
+            k[1, 1, :, :] = rng.integers(-1, 2, size=shape[2:])
+            b = rng.integers(0, 3, size=shape[-1]).astype(np.float32)
+        else:
+            k = (rng.standard_normal(shape) * 0.01).astype(np.float32)
+            b = np.zeros(shape[-1], np.float32)
+        w[name] = (k, b)
+    w = bf16_rounded(w)
+    m.set_weights(w)
+    x = rng.integers(-1, 2, size=(5, 11, 48, 3)).astype(np.float32)
+    xd = ctx.to_device(x, torch.bfloat16)
+    names = ["rrdb_0_dense1_conv2", "rrdb_0_dense1_conv3", "rrdb_0_dense1_conv5", "rrdb_0_dense2_conv5", "rrdb_0_dense3_conv5"]
+    ctx.set_fused(0, 0)
+    _, t0 = m.forward_with_taps(xd, names)
+    ctx.set_fused(3, 2)
+    _, t1 = m.forward_with_taps(xd, names)
+    # conv outputs are integers; x + 0.2*conv5 is not, but both paths round the same fp32 value
+    for n in names[:2]:
+        a, b = t0[n].cpu().numpy(), t1[n].cpu().numpy()
+        assert np.array_equal(a, b), (n, float(np.abs(a - b).max()), np.argwhere(a != b)[:5])
+    for n in names[2:]:
+        a, b = t0[n].cpu().numpy(), t1[n].cpu().numpy()
+        assert np.abs(a - b).max() <= 2.0 ** -7 * max(1.0, np.abs(a).max()), (n, float(np.abs(a - b).max()))
