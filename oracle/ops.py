@@ -276,6 +276,145 @@ def bicubic_resize_u8(img, out_h, out_w):
 
 
 # --------------------------------------------------------------------------------------
+# cv2.resize with INTER_LINEAR / INTER_AREA / INTER_LANCZOS4 (classic_algorithms.py:7-21; the per-file codes of
+# interpolation_map.pkl in loading_methods.py:131-148).  OpenCV (imgproc/resize.cpp) is not vendored by the reference and not
+# installed here: its published algorithm is restated -- per axis a table of (clamped source index, weight) taps, a horizontal
+# pass into float rows, then a vertical pass -- with the coefficient formulas of resizeGeneric / interpolateLanczos4 /
+# computeResizeAreaTab.
+# --------------------------------------------------------------------------------------
+INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 1, 2, 3, 4
+
+
+def lanczos4_coeffs(x):
+    """OpenCV interpolateLanczos4: 8 taps at floor-3 .. floor+4 for a fractional offset x (float32 results)."""
+    s45 = 0.70710678118654752440084436210485
+    cs = [(1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1), (-s45, s45)]
+    x = float(np.float32(x))
+    if x < np.finfo(np.float32).eps:
+        c = np.zeros(8, np.float32)
+        c[3] = 1.0
+        return c
+    y0 = -(x + 3) * math.pi * 0.25
+    s0, c0 = math.sin(y0), math.cos(y0)
+    c = np.zeros(8, np.float32)
+    total = np.float32(0)
+    for i in range(8):
+        y = -(x + 3 - i) * math.pi * 0.25
+        c[i] = np.float32((cs[i][0] * s0 + cs[i][1] * c0) / (y * y))
+        total = np.float32(total + c[i])
+    return (c * np.float32(np.float32(1.0) / total)).astype(np.float32)
+
+
+def resize_axis_taps(n_src, n_dst, interpolation, area_up=False):
+    """-> (idx [n_dst, T] clamped source indices, w [n_dst, T] float32 weights) for one axis."""
+    scale = 1.0 / (float(n_dst) / float(n_src))                   # OpenCV: inv_scale = dsize/ssize; scale = 1/inv_scale
+    inv_scale = float(n_dst) / float(n_src)
+    if interpolation == INTER_AREA and not area_up:               # true area (shrinking): computeResizeAreaTab
+        rows = []
+        for d in range(n_dst):
+            f1 = d * scale
+            f2 = f1 + scale
+            cell = min(scale, n_src - f1)
+            s1, s2 = math.ceil(f1), math.floor(f2)
+            s2 = min(s2, n_src - 1)
+            s1 = min(s1, s2)
+            taps = []
+            if s1 - f1 > 1e-3:
+                taps.append((s1 - 1, np.float32((s1 - f1) / cell)))
+            for sx in range(s1, s2):
+                taps.append((sx, np.float32(1.0 / cell)))
+            if f2 - s2 > 1e-3:
+                taps.append((s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+            rows.append(taps)
+        T = max(len(r) for r in rows)
+        idx = np.zeros((n_dst, T), np.int64)
+        w = np.zeros((n_dst, T), np.float32)
+        for d, taps in enumerate(rows):
+            for k, (i, a) in enumerate(taps):
+                idx[d, k], w[d, k] = i, a
+        return idx, w
+    d = np.arange(n_dst, dtype=np.float64)
+    if interpolation in (INTER_LINEAR, INTER_AREA):
+        if interpolation == INTER_AREA:                           # INTER_AREA asked to enlarge: linear taps, "area" coordinates
+            s = np.floor(d * scale).astype(np.int64)
+            f = ((d + 1) - (s + 1) * inv_scale).astype(np.float32)
+            f = np.where(f <= 0, np.float32(0), f - np.floor(f)).astype(np.float32)
+        else:
+            fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+            s = np.floor(fx).astype(np.int64)
+            f = (fx - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f = np.where(lo, np.float32(0), f)
+        s = np.where(lo, 0, s)
+        hi = s >= n_src - 1
+        f = np.where(hi, np.float32(0), f)
+        s = np.where(hi, n_src - 1, s)
+        idx = np.clip(np.stack([s, s + 1], axis=1), 0, n_src - 1)
+        w = np.stack([np.float32(1) - f, f], axis=1).astype(np.float32)
+        return idx, w
+    if interpolation == INTER_LANCZOS4:
+        fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(fx).astype(np.int64)
+        f = (fx - s.astype(np.float32)).astype(np.float32)
+        s, f = np.where(f >= 1, s + 1, s), np.where(f >= 1, np.float32(0), f)      # (s, 1.0) == (s + 1, 0.0)
+        idx = np.clip(s[:, None] + np.arange(-3, 5)[None, :], 0, n_src - 1)
+        w = np.stack([lanczos4_coeffs(v) for v in f])
+        return idx, w
+    if interpolation == INTER_CUBIC:
+        return _cubic_axis(n_src, n_dst, np.float32)
+    raise ValueError(f"interpolation code {interpolation}")
+
+
+def cv_resize(img, out_h, out_w, interpolation):
+    """cv2.resize(img, (out_w, out_h), interpolation=...) for float32 images [H,W,C] / [B,H,W,C]: horizontal pass into float
+    rows, then the vertical pass (taps in ascending source order), no clipping."""
+    img = np.asarray(img, np.float32)
+    squeeze = img.ndim == 3
+    if squeeze:
+        img = img[None]
+    B, H, W, C = img.shape
+    area_up = interpolation == INTER_AREA and not (out_w <= W and out_h <= H)
+    ix, wx = resize_axis_taps(W, out_w, interpolation, area_up)
+    iy, wy = resize_axis_taps(H, out_h, interpolation, area_up)
+    tmp = np.zeros((B, H, out_w, C), np.float32)
+    for k in range(ix.shape[1]):
+        tmp += img[:, :, ix[:, k], :] * wx[None, None, :, k, None]
+    out = np.zeros((B, out_h, out_w, C), np.float32)
+    for k in range(iy.shape[1]):
+        out += tmp[:, iy[:, k], :, :] * wy[None, :, k, None, None]
+    return out[0] if squeeze else out
+
+
+def cv_resize_u8(img, out_h, out_w, interpolation):
+    """uint8 path of cv2.resize for INTER_LINEAR / INTER_AREA (enlarging) / INTER_LANCZOS4 / INTER_CUBIC: 11-bit fixed-point taps
+    (saturate_cast<short>(w * 2048)), integer horizontal pass; vertical pass = OpenCV's VResizeLinear<uchar> special form for the
+    2-tap kernels, the generic 22-bit rounding shift otherwise."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8
+    H, W, C = img.shape
+    area_up = interpolation == INTER_AREA and not (out_w <= W and out_h <= H)
+    if interpolation == INTER_AREA and not area_up:
+        raise NotImplementedError("uint8 INTER_AREA shrinking is not restated")
+    ix, wx = resize_axis_taps(W, out_w, interpolation, area_up)
+    iy, wy = resize_axis_taps(H, out_h, interpolation, area_up)
+    iwx = np.clip(np.rint(wx * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    iwy = np.clip(np.rint(wy * np.float32(2048.0)), -32768, 32767).astype(np.int64)
+    src = img.astype(np.int64)
+    tmp = np.zeros((H, out_w, C), np.int64)
+    for k in range(ix.shape[1]):
+        tmp += src[:, ix[:, k], :] * iwx[None, :, k, None]
+    if ix.shape[1] == 2:
+        s0, s1 = tmp[iy[:, 0]], tmp[iy[:, 1]]
+        out = (((iwy[:, 0, None, None] * (s0 >> 4)) >> 16) + ((iwy[:, 1, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
+    else:
+        out = np.zeros((out_h, out_w, C), np.int64)
+        for k in range(iy.shape[1]):
+            out += tmp[iy[:, k]] * iwy[:, k, None, None]
+        out = (out + (1 << 21)) >> 22
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------
 # PSNR / SSIM, tf.image semantics (SURVEY.md A.3 / A.4; reference metrics.py:3-7)
 # --------------------------------------------------------------------------------------
 def psnr(a, b, max_val=1.0, dtype=np.float32):

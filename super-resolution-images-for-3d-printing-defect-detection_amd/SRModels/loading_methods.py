@@ -14,7 +14,9 @@ import numpy as np
 from PIL import Image
 
 _EXTS = (".jpg", ".jpeg", ".png", ".bmp", ".tiff")
-_CUBIC_CODES = ("INTER_CUBIC", 2)
+# interpolation_map.pkl holds, per file name, an OpenCV constant name or its integer code (loading_methods.py:131-148); unknown
+# names fall back to INTER_CUBIC as in the reference
+_INTERP_CODES = {"INTER_LINEAR": 1, "INTER_CUBIC": 2, "INTER_AREA": 3, "INTER_LANCZOS4": 4}
 
 
 def add_padding(image, patch_size, stride):
@@ -50,10 +52,10 @@ def _check_dirs(*roots):
             raise ValueError("Both HR and LR root paths must be directories.")
 
 
-def _bicubic_up(lr_img, hr_h, hr_w):
+def _resize_up(lr_img, hr_h, hr_w, code=2):
     from sr355 import Context
     ctx = Context.get()
-    return ctx.bicubic(ctx.to_device(lr_img[None]), hr_h, hr_w)[0].cpu().numpy()
+    return ctx.resize(ctx.to_device(lr_img[None]), hr_h, hr_w, code)[0].cpu().numpy()
 
 
 def load_dataset_as_patches(hr_root, lr_root, mode="srcnn", patch_size=33, stride=14, scale_factor=2, interpolation_map_path=None):
@@ -82,10 +84,9 @@ def load_dataset_as_patches(hr_root, lr_root, mode="srcnn", patch_size=33, strid
         hr_img, lr_img = _read_rgb01(hr_by[fname]), _read_rgb01(lr_by[fname])
         hr_h, hr_w = hr_img.shape[:2]
         if mode == "srcnn":
-            method = interp_map.get(fname, "INTER_CUBIC") if interp_map is not None else "INTER_CUBIC"
-            if method not in _CUBIC_CODES:
-                raise NotImplementedError(f"{fname}: interpolation {method!r}; only INTER_CUBIC is on the accelerated path")
-            lr_up = np.clip(_bicubic_up(lr_img, hr_h, hr_w), 0.0, 1.0)
+            method = interp_map.get(fname, 2) if interp_map is not None else 2
+            code = _INTERP_CODES.get(method, 2) if isinstance(method, str) else int(method) if isinstance(method, (int, np.integer)) else 2
+            lr_up = np.clip(_resize_up(lr_img, hr_h, hr_w, code), 0.0, 1.0)
             hr_p, lr_p = add_padding(hr_img, patch_size, stride), add_padding(lr_up, patch_size, stride)
             for i, j in _windows(hr_p.shape[0], hr_p.shape[1], patch_size, stride):   # padded extents
                 X.append(lr_p[i:i + patch_size, j:j + patch_size])

@@ -845,6 +845,13 @@ int sr_bicubic(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C
     return bicubic_launch(ctx, x, dtype, B, H, W, C, outH, outW, y, dtype, C, static_cast<hipStream_t>(stream));
 }
 
+int sr_resize(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, int interpolation, void* y, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!x || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return resize_launch(ctx, x, dtype, B, H, W, C, outH, outW, interpolation, y, static_cast<hipStream_t>(stream));
+}
+
 int sr_psnr(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float max_val, float* out_B, void* stream) {
     DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;

@@ -44,6 +44,7 @@ struct sr_ctx {
     // kernels whose dynamic-LDS ceiling has been raised on THIS context's device (hipFuncSetAttribute is per device)
     std::unordered_set<const void*> lds_attr_done;
     int ensure_dyn_lds(const void* kernel, int bytes);
+    void* tab_buf = nullptr; size_t tab_cap = 0;   // tap tables of sr_resize (stream-ordered reuse)
     void* zero_page = nullptr;    // 4 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int chain_mask = 3;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3 (sr_debug_set_fused; default both)
@@ -163,6 +164,7 @@ int dense_launch(sr_ctx* ctx, const float* x, const float* w, const float* bias,
                  float* y, int y_dtype, void* y_typed, hipStream_t st);
 int bicubic_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW,
                    void* y, int out_dtype, int64_t y_cs, hipStream_t st);
+int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, int interp, void* y, hipStream_t st);
 int psnr_launch(sr_ctx* ctx, const float* a, const float* b, int B, int64_t n_per_image, float max_val, float* out,
                 hipStream_t st);
 int ssim_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float max_val, float* out,

@@ -659,3 +659,157 @@ int clock_probe_launch(sr_ctx* ctx, float* mhz_out, hipStream_t st) {
     *mhz_out = (float)f[f.size() / 2];
     return SR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// cv2.resize for INTER_LINEAR / INTER_AREA / INTER_LANCZOS4 (classic_algorithms.py:7-21, the per-file codes of
+// interpolation_map.pkl: loading_methods.py:131-148).  Two tiny kernels build the per-axis tap tables (clamped source index +
+// weight, OpenCV's resizeGeneric / interpolateLanczos4 / computeResizeAreaTab formulas), one kernel applies them: horizontal taps
+// first, rounded to the row type, then the vertical taps -- the order of OpenCV's two passes.
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_MAXT = 16;
+
+__global__ void resize_taps_kernel(int n_src, int n_dst, int interp, int area_up, int T, int* idx, float* w, int* iw) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dst) return;
+    const double inv_scale = (double)n_dst / (double)n_src, scale = 1.0 / inv_scale;
+    int* id = idx + (size_t)d * T;
+    float* wd = w + (size_t)d * T;
+    for (int k = 0; k < T; ++k) { id[k] = 0; wd[k] = 0.f; }
+    if (interp == 3 && !area_up) {                                 // INTER_AREA, shrinking
+        // (explicit *_rn operations throughout: a contracted fma changes which side of an integer a coordinate falls on -- OpenCV's
+        //  x86 builds round the product first)
+        const double f1 = __dmul_rn((double)d, scale), f2 = __dadd_rn(f1, scale);
+        const double cell = fmin(scale, (double)n_src - f1);
+        int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+        s2 = min(s2, n_src - 1);
+        s1 = min(s1, s2);
+        int k = 0;
+        if (s1 - f1 > 1e-3) { id[k] = s1 - 1; wd[k] = (float)((s1 - f1) / cell); ++k; }
+        for (int sx = s1; sx < s2 && k < T; ++sx, ++k) { id[k] = sx; wd[k] = (float)(1.0 / cell); }
+        if (f2 - s2 > 1e-3 && k < T) { id[k] = s2; wd[k] = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell); ++k; }
+    } else if (interp == 1 || interp == 3) {                       // linear taps; INTER_AREA enlarging uses "area" coordinates
+        int s; float f;
+        if (interp == 3) {
+            s = (int)floor(__dmul_rn((double)d, scale));
+            f = (float)__dsub_rn((double)(d + 1), __dmul_rn((double)(s + 1), inv_scale));
+            f = f <= 0.f ? 0.f : f - floorf(f);
+        } else {
+            const float fx = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+            s = (int)floorf(fx);
+            f = fx - (float)s;
+        }
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+        id[0] = min(max(s, 0), n_src - 1); id[1] = min(max(s + 1, 0), n_src - 1);
+        wd[0] = 1.f - f; wd[1] = f;
+    } else {                                                       // INTER_LANCZOS4: 8 taps at s-3 .. s+4
+        const float fx = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+        int s = (int)floorf(fx);
+        float x = fx - (float)s;
+        if (x >= 1.f) { s += 1; x = 0.f; }                           // fx a hair below an integer: (s, 1.0) is (s + 1, 0.0) -- and 1.0 would divide by zero below
+        for (int k = 0; k < 8; ++k) id[k] = min(max(s - 3 + k, 0), n_src - 1);
+        if (x < 1.1920929e-07f) { wd[3] = 1.f; }
+        else {
+            const double s45 = 0.70710678118654752440084436210485;
+            const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+            const double y0 = -((double)x + 3) * 3.14159265358979323846 * 0.25, s0 = sin(y0), c0 = cos(y0);
+            float sum = 0.f, c[8];
+            for (int k = 0; k < 8; ++k) {
+                const double y = -((double)x + 3 - k) * 3.14159265358979323846 * 0.25;
+                c[k] = (float)((cs[k][0] * s0 + cs[k][1] * c0) / (y * y));
+                sum += c[k];
+            }
+            sum = 1.f / sum;
+            for (int k = 0; k < 8; ++k) wd[k] = c[k] * sum;
+        }
+    }
+    if (iw) for (int k = 0; k < T; ++k) {                          // saturate_cast<short>(w * INTER_RESIZE_COEF_SCALE)
+        const float v = rintf(wd[k] * 2048.f);
+        iw[(size_t)d * T + k] = (int)fminf(fmaxf(v, -32768.f), 32767.f);
+    }
+}
+
+__global__ void resize_apply_f32_kernel(const float* x, int B, int H, int W, int C, int oH, int oW, int TX, int TY, const int* ix, const float* wx,
+                                        const int* iy, const float* wy, float* y) {
+    const int64_t n = (int64_t)B * oH * oW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % oW); t /= oW;
+        const int oy = (int)(t % oH);
+        const int b = (int)(t / oH);
+        float acc = 0.f;
+        for (int j = 0; j < TY; ++j) {
+            const float wyj = wy[oy * TY + j];
+            const float* row = x + ((int64_t)b * H + iy[oy * TY + j]) * W * C + c;
+            float r = 0.f;
+            for (int k = 0; k < TX; ++k) r = __fadd_rn(r, __fmul_rn(row[(int64_t)ix[ox * TX + k] * C], wx[ox * TX + k]));
+            acc = __fadd_rn(acc, __fmul_rn(r, wyj));
+        }
+        y[i] = acc;
+    }
+}
+
+__global__ void resize_apply_u8_kernel(const uint8_t* x, int B, int H, int W, int C, int oH, int oW, int TX, int TY, const int* ix, const int* iwx,
+                                       const int* iy, const int* iwy, uint8_t* y) {
+    const int64_t n = (int64_t)B * oH * oW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % oW); t /= oW;
+        const int oy = (int)(t % oH);
+        const int b = (int)(t / oH);
+        long long rows[RS_MAXT];
+        for (int j = 0; j < TY; ++j) {
+            const uint8_t* row = x + ((int64_t)b * H + iy[oy * TY + j]) * W * C + c;
+            long long r = 0;
+            for (int k = 0; k < TX; ++k) r += (long long)row[(int64_t)ix[ox * TX + k] * C] * iwx[ox * TX + k];
+            rows[j] = r;
+        }
+        long long v;
+        if (TX == 2 && TY == 2) v = (((iwy[oy * 2] * (rows[0] >> 4)) >> 16) + ((iwy[oy * 2 + 1] * (rows[1] >> 4)) >> 16) + 2) >> 2;   // VResizeLinear<uchar>
+        else {
+            v = 0;
+            for (int j = 0; j < TY; ++j) v += rows[j] * iwy[oy * TY + j];
+            v = (v + (1 << 21)) >> 22;
+        }
+        y[i] = (uint8_t)min(max(v, 0ll), 255ll);
+    }
+}
+
+int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, int interp, void* y, hipStream_t st) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || outH <= 0 || outW <= 0) return ctx->fail(SR_ERR_INVALID, "resize: empty tensor");
+    if (dtype != SR_DTYPE_F32 && dtype != SR_DTYPE_U8) return ctx->fail(SR_ERR_INVALID, "resize: dtype must be f32 or u8");
+    if (interp == 2) return bicubic_launch(ctx, x, dtype, B, H, W, C, outH, outW, y, dtype, C, st);
+    if (interp != 1 && interp != 3 && interp != 4) return ctx->fail(SR_ERR_INVALID, "resize: interpolation must be INTER_LINEAR (1), INTER_CUBIC (2), INTER_AREA (3) or INTER_LANCZOS4 (4)");
+    const bool shrink_both = outW <= W && outH <= H;
+    const int area_up = interp == 3 && !shrink_both;
+    auto taps = [&](int ns, int nd) { return interp == 4 ? 8 : (interp == 3 && !area_up) ? (int)ceil((double)ns / nd) + 2 : 2; };
+    const int TX = taps(W, outW), TY = taps(H, outH);
+    if (TX > RS_MAXT || TY > RS_MAXT) return ctx->fail(SR_ERR_INVALID, "resize: INTER_AREA shrink factor above 14 is not supported");
+    if (dtype == SR_DTYPE_U8 && interp == 3 && !area_up) return ctx->fail(SR_ERR_INVALID, "resize: uint8 INTER_AREA shrinking is not built");
+    const size_t nx = (size_t)outW * TX, ny = (size_t)outH * TY, need = (nx + ny) * 12;
+    if (need > ctx->tab_cap) {
+        if (ctx->tab_buf) { SR_HIP(ctx, hipDeviceSynchronize()); ctx->dfree(ctx->tab_buf); ctx->tab_buf = nullptr; ctx->tab_cap = 0; }
+        ctx->tab_buf = ctx->dalloc(need);
+        if (!ctx->tab_buf) return SR_ERR_OOM;
+        ctx->tab_cap = need;
+    }
+    int* ix = static_cast<int*>(ctx->tab_buf);
+    float* wx = reinterpret_cast<float*>(ix + nx);
+    int* iwx = reinterpret_cast<int*>(wx + nx);
+    int* iy = iwx + nx;
+    float* wy = reinterpret_cast<float*>(iy + ny);
+    int* iwy = reinterpret_cast<int*>(wy + ny);
+    hipLaunchKernelGGL(resize_taps_kernel, dim3((outW + 255) / 256), dim3(256), 0, st, W, outW, interp, area_up, TX, ix, wx, iwx);
+    hipLaunchKernelGGL(resize_taps_kernel, dim3((outH + 255) / 256), dim3(256), 0, st, H, outH, interp, area_up, TY, iy, wy, iwy);
+    const int64_t n = (int64_t)B * outH * outW * C;
+    if (dtype == SR_DTYPE_F32)
+        hipLaunchKernelGGL(resize_apply_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const float*>(x), B, H, W, C, outH, outW, TX, TY, ix, wx, iy, wy,
+                           static_cast<float*>(y));
+    else
+        hipLaunchKernelGGL(resize_apply_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const uint8_t*>(x), B, H, W, C, outH, outW, TX, TY, ix, iwx, iy, iwy,
+                           static_cast<uint8_t*>(y));
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sr_conv2d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _f, _vp, _f, _vp, _f, _i, _i, _vp, _vp]),
     "sr_self_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
     "sr_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sr_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_psnr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),

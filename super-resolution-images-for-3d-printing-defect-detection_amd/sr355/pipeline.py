@@ -99,3 +99,80 @@ def sr_then_classify(sr_model, classifier, lr_img, sr_kwargs=None, patch_size=96
     sr, metrics = sr_model.super_resolve_image(lr, **(sr_kwargs or {}))
     cls, conf = classifier.classify_defects_method(sr, patch_size=patch_size, stride=stride, batch_size=batch_size)
     return sr, metrics, cls, conf
+
+
+def stream_sr_classify(sr_model, classifier, frames, sr_kwargs=None, patch_size=96, stride=48, batch_size=512, rank=0, world=1,
+                       keep_sr=False):
+    """BASELINE configs[4]: a stream of LR frames -> x4 super-resolution -> VGG16 patch vote per frame, everything between the host
+    frame and the (class, confidence) pair resident on the GPU.
+
+    Reconstructed from the helpers the reference wrote for its (missing) defect_detection_pipeline notebook: per frame
+    `super_resolve_image` (ESRGAN_model.py:858-979) then `classify_defects_method` on the SR image (VGG16_model.py:168-270); the
+    ingest contract is `load_predictions_dataset` (loading_methods.py:288-386): arrays of whole frames, uint8 or float RGB.
+
+    * frames are independent units: rank r of `world` takes the contiguous slice dist.shard_range gives it -- no data-path
+      collective (SURVEY.md 8e);
+    * double-buffered ingest: frame i+1 crosses PCIe (pinned staging, a second HIP stream) while frame i is in the generator;
+    * the SR frame never leaves HBM: the classifier's 96x96 patches are cut from it on the device.
+
+    frames: sequence of [H,W,3] arrays (uint8 [0,255] or float [0,1]) or device tensors.  Returns
+    ([{'frame', 'class', 'confidence', 'sr' (only if keep_sr)}...] for this rank's frames, stats dict)."""
+    from .dist import shard_range
+    ctx = sr_model.ctx
+    dev = ctx.torch_device
+    lo, hi = shard_range(len(frames), rank, world)
+    mine = list(range(lo, hi))
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    staged = [None, None]                                   # (device tensor, ready event) per buffer
+
+    def ingest(slot, idx):
+        f = frames[idx]
+        if isinstance(f, torch.Tensor):
+            t = f.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            staged[slot] = (t, ev)
+            return
+        a = np.ascontiguousarray(np.asarray(f))
+        host = torch.from_numpy(a).pin_memory()
+        with torch.cuda.stream(copy_stream):
+            t = host.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        staged[slot] = (t, ev, host)                        # keep the pinned buffer alive until the copy has been consumed
+
+    results = []
+    t_sr = t_cls = 0.0
+    out_pix = 0
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    if mine:
+        ingest(0, mine[0])
+    for k, idx in enumerate(mine):
+        cur = staged[k & 1]
+        if k + 1 < len(mine):
+            ingest((k + 1) & 1, mine[k + 1])                # next frame's copy overlaps this frame's compute
+        main.wait_event(cur[1])
+        x = cur[0]
+        lr = (x.to(torch.float32) / 255.0) if x.dtype == torch.uint8 else x.to(torch.float32)
+        a = time.perf_counter()
+        sr, _ = sr_model.super_resolve_image(lr.contiguous(), **(sr_kwargs or {}))
+        b = time.perf_counter()
+        cls, conf = classifier.classify_defects_method(sr, patch_size=patch_size, stride=stride, batch_size=batch_size)
+        c = time.perf_counter()                             # the vote needs the probabilities on the host: the frame is complete here
+        t_sr += b - a
+        t_cls += c - b
+        out_pix += int(sr.shape[0]) * int(sr.shape[1])
+        rec = {"frame": idx, "class": int(cls), "confidence": float(conf)}
+        if keep_sr:
+            rec["sr"] = sr
+        results.append(rec)
+        staged[k & 1] = None
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    n = max(len(mine), 1)
+    stats = {"frames": len(mine), "wall_s": wall, "frames_per_s": len(mine) / wall if wall > 0 else 0.0,
+             "sr_output_mpix_per_s": out_pix / 1e6 / wall if wall > 0 else 0.0,
+             "host_ms_per_frame_sr_enqueue_plus_wait": 1e3 * t_sr / n, "host_ms_per_frame_classify": 1e3 * t_cls / n}
+    return results, stats

@@ -171,6 +171,20 @@ class Context:
                                        self.stream()))
         return y
 
+    INTERPOLATIONS = {"INTER_LINEAR": 1, "INTER_CUBIC": 2, "INTER_AREA": 3, "INTER_LANCZOS4": 4}
+
+    def resize(self, x, out_h, out_w, interpolation="INTER_CUBIC"):
+        """cv2.resize(x, (out_w, out_h), interpolation): x [B,H,W,C] f32 or u8 tensor; interpolation = OpenCV name or code."""
+        code = self.INTERPOLATIONS.get(interpolation, interpolation)
+        if code not in (1, 2, 3, 4):
+            raise ValueError(f"unsupported interpolation {interpolation!r}")
+        _check_tensor(self, x, "resize input", (torch.float32, torch.uint8))
+        B, H, W, Cx = x.shape
+        y = self.empty((B, out_h, out_w, Cx), x.dtype)
+        self.check(self.lib.sr_resize(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, Cx, int(out_h), int(out_w), int(code), y.data_ptr(),
+                                      self.stream()))
+        return y
+
     def _metric(self, fn, a, b, max_val):
         _check_tensor(self, a, "metric input a")
         _check_tensor(self, b, "metric input b")

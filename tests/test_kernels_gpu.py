@@ -301,3 +301,52 @@ def test_extract_and_overlap_add(ctx, hw, p, s, scale):
     out = ctx.overlap_add(_dev(ctx, hr, torch.float32), hw[0], hw[1], p, s, scale).cpu().numpy()
     assert out.shape == ref.shape
     assert np.max(np.abs(out - ref)) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ cv2.resize family (sr_resize)
+RESIZE_CASES = [
+    # shape, (out_h, out_w)
+    ((1, 24, 20, 3), (48, 40)),       # x2 up: the loader's LR -> HR
+    ((2, 23, 31, 3), (46, 93)),       # x2 / x3 up, ragged
+    ((1, 17, 9, 1), (40, 37)),        # non-integer factors, single channel
+    ((1, 30, 42, 3), (30, 42)),       # same size
+]
+
+
+@pytest.mark.parametrize("interp", ["INTER_LINEAR", "INTER_AREA", "INTER_LANCZOS4", "INTER_CUBIC"])
+@pytest.mark.parametrize("shape,out", RESIZE_CASES)
+def test_resize_f32_matches_oracle(ctx, shape, out, interp):
+    x = np.random.default_rng(sum(shape) + out[0]).uniform(0, 1, shape).astype(np.float32)
+    code = {"INTER_LINEAR": O.INTER_LINEAR, "INTER_AREA": O.INTER_AREA, "INTER_LANCZOS4": O.INTER_LANCZOS4, "INTER_CUBIC": O.INTER_CUBIC}[interp]
+    ref = O.cv_resize(x, out[0], out[1], code)
+    got = ctx.resize(ctx.to_device(x), out[0], out[1], interp).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 2e-6, float(np.max(np.abs(got - ref)))
+    assert np.array_equal(got, ctx.resize(ctx.to_device(x), out[0], out[1], code).cpu().numpy())      # OpenCV integer code == name
+
+
+@pytest.mark.parametrize("shape,out", [((1, 48, 40, 3), (24, 20)), ((2, 37, 50, 3), (11, 17)), ((1, 64, 64, 3), (5, 9))])
+def test_resize_area_shrinking_f32(ctx, shape, out):
+    """INTER_AREA, both axes shrinking: weighted box average (computeResizeAreaTab); integer factors = plain block means."""
+    x = np.random.default_rng(3).uniform(0, 1, shape).astype(np.float32)
+    ref = O.cv_resize(x, out[0], out[1], O.INTER_AREA)
+    got = ctx.resize(ctx.to_device(x), out[0], out[1], "INTER_AREA").cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 2e-6
+    if shape[1] % out[0] == 0 and shape[2] % out[1] == 0:
+        fy, fx = shape[1] // out[0], shape[2] // out[1]
+        assert np.max(np.abs(got - x.reshape(shape[0], out[0], fy, out[1], fx, shape[3]).mean(axis=(2, 4)))) <= 1e-6
+
+
+@pytest.mark.parametrize("interp", ["INTER_LINEAR", "INTER_AREA", "INTER_LANCZOS4", "INTER_CUBIC"])
+def test_resize_u8_bit_exact(ctx, interp):
+    rng = np.random.default_rng(5)
+    for shape, out in (((1, 24, 20, 3), (48, 40)), ((1, 19, 23, 3), (50, 31)), ((1, 8, 8, 1), (8, 9))):
+        x = rng.integers(0, 256, shape, dtype=np.uint8)
+        code = ctx.INTERPOLATIONS[interp]
+        ref = O.cv_resize_u8(x[0], out[0], out[1], code)
+        got = ctx.resize(ctx.to_device(x, torch.uint8), out[0], out[1], interp).cpu().numpy()[0]
+        assert np.array_equal(got, ref), (shape, out, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+    with pytest.raises(ValueError):
+        ctx.resize(ctx.to_device(x, torch.uint8), 4, 4, "INTER_AREA")          # uint8 shrinking area: not built
+    with pytest.raises(ValueError):
+        ctx.resize(ctx.to_device(x, torch.uint8), 16, 16, "INTER_NEAREST")

@@ -141,12 +141,14 @@ def test_sr_then_classify_pipeline(ctx):
     assert cls == rcls and abs(conf - rconf) <= 1e-4 and "time_sec" in met
 
 
-def test_whole_image_attention_sampled_rows(ctx):
-    """SelfAttention on a whole 128x128 feature map (N = 16384: the score matrix would be 2 GB in fp64 and is never
-    materialised on either side): the HIP streaming-softmax kernel against the fp64 streaming oracle on sampled query rows."""
+@pytest.mark.parametrize("side", [128, 512])
+def test_whole_image_attention_sampled_rows(ctx, side):
+    """SelfAttention on a whole feature map -- 128x128 (N = 16384) and the 512x512 LR tile of BASELINE configs[2] (N = 262144: the
+    score matrix would be 550 GB in fp64 and is never materialised on either side): the HIP streaming-softmax kernel
+    against the fp64 streaming oracle on sampled query rows."""
     from sr355.weights import init_weights
     rng = np.random.default_rng(21)
-    H = W = 128
+    H = W = side
     x = (0.5 * rng.standard_normal((1, H, W, 64))).astype(np.float32)
     w = init_weights(M.self_attention_layers("sa"), seed=5)
     y = ctx.self_attention(ctx.to_device(x), *w["sa_f"], *w["sa_g"], *w["sa_h"], *w["sa_v"]).cpu().numpy()
@@ -186,3 +188,116 @@ def test_full_depth_generator_bf16_tracks_fp32(ctx):
     # patch); here the whole patch-mode pipeline, overlap-averaged
     assert d >= 40.0, d
     assert abs(out["f32"][1] - out["bf16"][1]) <= 0.02, (out["f32"][1], out["bf16"][1])   # PSNR vs HR: north-star bar is 0.01 dB on trained nets
+
+
+def test_classic_resizers_and_srcnn_mode_loader_with_interpolation_map(ctx, tmp_path):
+    """classic_algorithms.py:7-21 through the reference-shaped wrappers, and load_dataset_as_patches(mode="srcnn") on a dataset whose
+    interpolation_map.pkl names a different OpenCV interpolation per file -- constant names and integer codes, as
+    loading_methods.py:131-148 accepts them -- against the oracle's restatement of the same loop."""
+    import os
+    import pickle
+    from PIL import Image
+    from SRModels import loading_methods as LM
+    from SRModels.classic_super_resolution_algorithms import classic_algorithms as CA
+    rng = np.random.default_rng(12)
+    lr = rng.uniform(0, 1, (20, 26, 3)).astype(np.float32)
+    for fn, code in ((CA.interpolate_bilinear, O.INTER_LINEAR), (CA.interpolate_area, O.INTER_AREA), (CA.interpolate_lanczos, O.INTER_LANCZOS4),
+                     (CA.interpolate_bicubic, O.INTER_CUBIC)):
+        up = fn(lr, (52, 40))                                     # (width, height), as cv2.resize takes it
+        assert up.shape == (40, 52, 3) and up.dtype == np.float32
+        assert np.max(np.abs(up - O.cv_resize(lr, 40, 52, code))) <= 2e-6
+        u8 = (lr * 255).astype(np.uint8)
+        assert np.array_equal(fn(u8, (52, 40)), O.cv_resize_u8(u8, 40, 52, code))
+        assert fn(lr[:, :, 0], (52, 40)).shape == (40, 52)        # grayscale in, grayscale out
+    with pytest.raises(NotImplementedError):
+        CA.back_projection(lr, lr)
+    # ---- the loader
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "hr"))
+    os.makedirs(os.path.join(root, "lr"))
+    names = ["a.png", "b.png", "c.png", "d.png", "e.png"]
+    methods = {"a.png": "INTER_LINEAR", "b.png": "INTER_AREA", "c.png": 4, "d.png": "INTER_SOMETHING_ELSE"}     # e.png: not in the map -> cubic
+    imgs = {}
+    for n in names:
+        h = rng.integers(0, 256, (40, 36, 3), dtype=np.uint8)
+        l = h.reshape(20, 2, 18, 2, 3).mean(axis=(1, 3)).astype(np.uint8)
+        Image.fromarray(h).save(os.path.join(root, "hr", n))
+        Image.fromarray(l).save(os.path.join(root, "lr", n))
+        imgs[n] = (h.astype(np.float32) / 255.0, l.astype(np.float32) / 255.0)
+    mp = os.path.join(root, "interpolation_map.pkl")
+    with open(mp, "wb") as f:
+        pickle.dump(methods, f)
+    X, Y, hh, ww = LM.load_dataset_as_patches(os.path.join(root, "hr"), os.path.join(root, "lr"), mode="srcnn", patch_size=12, stride=6,
+                                              interpolation_map_path=mp)
+    codes = {"a.png": O.INTER_LINEAR, "b.png": O.INTER_AREA, "c.png": O.INTER_LANCZOS4, "d.png": O.INTER_CUBIC, "e.png": O.INTER_CUBIC}
+    Xr, Yr = [], []
+    for n in names:
+        h, l = imgs[n]
+        up = np.clip(O.cv_resize(l, 40, 36, codes[n]), 0.0, 1.0)
+        hp, lp = O.add_padding(h, 12, 6), O.add_padding(up, 12, 6)
+        for i, j in O.patch_positions(hp.shape[0], hp.shape[1], 12, 6):
+            Xr.append(lp[i:i + 12, j:j + 12])
+            Yr.append(hp[i:i + 12, j:j + 12])
+    assert (hh, ww) == (40, 36) and X.shape == np.array(Xr).shape and np.array_equal(Y, np.array(Yr))
+    assert np.max(np.abs(X - np.array(Xr))) <= 2e-6
+    # without a map every file takes INTER_CUBIC (the reference raises NameError there: SURVEY.md Appendix C.1)
+    X2, _, _, _ = LM.load_dataset_as_patches(os.path.join(root, "hr"), os.path.join(root, "lr"), mode="srcnn", patch_size=12, stride=6)
+    up = np.clip(O.cv_resize(imgs["a.png"][1], 40, 36, O.INTER_CUBIC), 0.0, 1.0)
+    assert np.max(np.abs(X2[0] - O.add_padding(up, 12, 6)[:12, :12])) <= 2e-6
+
+
+def test_streaming_sr_then_classify_frames(ctx):
+    """BASELINE configs[4] on small frames: a stream of uint8 / float frames through ESRGAN x4 and the VGG16 vote, frame by frame
+    against the oracle; the rank shards partition the stream."""
+    from sr355.pipeline import stream_sr_classify
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    from SRModels.defect_detection_models.VGG16_model import FineTunedVGG16
+    g = ESRGAN(compute_dtype="f32")
+    g.setup_model(scale_factor=4, growth_channels=8, num_rrdb_blocks=1)
+    g.set_weights(g.weights)
+    c = FineTunedVGG16()
+    c.setup_model(input_shape=(96, 96, 3), num_classes=2)
+    lr, _ = make_pairs(5, 40, 36, 4, seed=18)
+    frames = [lr[0], (lr[1] * 255).astype(np.uint8), lr[2], ctx.to_device(lr[3]), lr[4]]          # float, uint8, float, device tensor, float
+    kw = dict(patch_size_lr=24, stride=12, batch_size=64)
+    res, stats = stream_sr_classify(g, c, frames, sr_kwargs=kw, keep_sr=True)
+    assert [r["frame"] for r in res] == [0, 1, 2, 3, 4] and stats["frames"] == 5 and stats["frames_per_s"] > 0
+    for r in res:
+        f = frames[r["frame"]]
+        f = f.cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f)
+        f01 = f.astype(np.float32) / 255.0 if f.dtype == np.uint8 else f
+        ref_sr = M.esrgan_super_resolve(f01, g.weights, 4, 24, 12, num_rrdb=1, dtype=np.float64)
+        assert np.max(np.abs(r["sr"].cpu().numpy() - ref_sr)) <= 1e-5
+        rcls, rconf = M.classify_defects(ref_sr.astype(np.float32), c.weights, 96, 48, dtype=np.float64)
+        assert r["class"] == rcls and abs(r["confidence"] - rconf) <= 1e-4
+    parts = [stream_sr_classify(g, c, frames, sr_kwargs=kw, rank=r, world=2)[0] for r in range(2)]
+    assert [x["frame"] for x in parts[0]] == [0, 1, 2] and [x["frame"] for x in parts[1]] == [3, 4]
+    assert [(x["class"], x["confidence"]) for p_ in parts for x in p_] == [(r["class"], r["confidence"]) for r in res]
+
+
+def test_streaming_pipeline_full_size_frame_properties(ctx):
+    """One 1080x1920 frame through the bench generator (x4, NB=23, G=32, bf16) and the bf16 classifier: 45 x 80 = 3600 LR patches,
+    a 4320 x 7680 SR frame, 90 x 160 = 14400 classifier patches.  Size-independent properties only (the
+    oracle needs minutes per frame): shape, range, finiteness, the patch counts, and the same (class, confidence) on a second pass."""
+    from sr355.pipeline import patch_grid, stream_sr_classify
+    from sr355.synth import hr_tile
+    from sr355.weights import condition_attention, init_weights
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    from SRModels.defect_detection_models.VGG16_model import FineTunedVGG16
+    g = ESRGAN(compute_dtype="bf16")
+    g.setup_model(scale_factor=4, growth_channels=32, num_rrdb_blocks=23)
+    g.set_weights(condition_attention(init_weights(g.generator.layer_shapes(), seed=3000)))
+    c = FineTunedVGG16(compute_dtype="bf16")
+    c.setup_model(input_shape=(96, 96, 3), num_classes=2)
+    c.set_weights(c.weights)
+    frame = (hr_tile(np.random.default_rng(4), 1080, 1920) * 255).astype(np.uint8)
+    assert patch_grid(1080, 1920, 48, 24) == (45, 80) and patch_grid(4320, 7680, 96, 48) == (90, 160)
+    kw = dict(patch_size_lr=48, stride=24, batch_size=3600)
+    res, stats = stream_sr_classify(g, c, [frame, frame], sr_kwargs=kw, batch_size=1024, keep_sr=True)
+    sr = res[0]["sr"]
+    assert tuple(sr.shape) == (4320, 7680, 3) and bool(torch.isfinite(sr).all()) and float(sr.min()) >= 0.0 and float(sr.max()) <= 1.0
+    assert (res[0]["class"], res[0]["confidence"]) == (res[1]["class"], res[1]["confidence"]) and torch.equal(res[0]["sr"], res[1]["sr"])
+    assert res[0]["class"] in (0, 1) and 0.0 < res[0]["confidence"] <= 1.0
+    print(f"\n1080p frame: {stats['frames_per_s']:.2f} frames/s, {stats['sr_output_mpix_per_s']:.1f} SR MPix/s (first frame includes workspace allocation)")
+    g.generator.release_workspace()
+    c.model.release_workspace()
