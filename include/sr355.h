@@ -38,7 +38,9 @@ typedef enum sr_status {
 } sr_status;
 
 enum { SR_DTYPE_F32 = 0, SR_DTYPE_BF16 = 1, SR_DTYPE_U8 = 2 };
-enum { SR_MODEL_SRCNN = 0, SR_MODEL_EDSR = 1, SR_MODEL_ESRGAN_G = 2, SR_MODEL_VGG16 = 3 };
+enum { SR_MODEL_SRCNN = 0, SR_MODEL_EDSR = 1, SR_MODEL_ESRGAN_G = 2, SR_MODEL_VGG16 = 3,
+       SR_MODEL_ESRGAN_D = 4,          /* discriminator, inference graph (ESRGAN_model.py:347-377): [B,H,W,3] in [-1,1] -> [B,1] probabilities */
+       SR_MODEL_VGG19_FEATURES = 5 };  /* perceptual-loss extractor incl. preprocessing (ESRGAN_model.py:379-408): -> [B,H/16,W/16,512]     */
 enum { SR_ACT_LINEAR = 0, SR_ACT_RELU = 1, SR_ACT_LRELU = 2, SR_ACT_TANH = 3 };
 enum { SR_WEIGHT_KERNEL = 0, SR_WEIGHT_BIAS = 1 };
 
@@ -115,11 +117,11 @@ int  sr_model_finalize(sr_model* m);
  * the reference's tf.keras.backend.clear_session() between runs (defect_detection_pipeline / notebooks). */
 int  sr_model_release_workspace(sr_model* m);
 /* Diagnostics for stage-by-stage parity traces (tests/): the graph as a flat op list -- name = Keras layer name of a
- * conv (ESRGAN_model.py:230-341), else the op kind; the op's output is [B, (H*mul)>>shift, (W*mul)>>shift, channels]
- * (channels 0: no tensor output) -- and a tap that copies op `op_index`'s output, as dense fp32 NHWC, into
+ * conv (ESRGAN_model.py:230-341), else the op kind; the op's output is [B, h, w, channels] with h = (H*mul)>>shift then
+ * ceil-halved ceil_halvings times (stride-2 SAME convs), w likewise (channels 0: no tensor output) -- and a tap that copies op `op_index`'s output, as dense fp32 NHWC, into
  * `device_dst` during every later sr_forward (NULL removes the tap).  Never set in production runs. */
 int  sr_model_num_ops(sr_model* m);
-int  sr_model_op_info(sr_model* m, int index, const char** name, int* channels, int* mul, int* shift);
+int  sr_model_op_info(sr_model* m, int index, const char** name, int* channels, int* mul, int* shift, int* ceil_halvings);
 int  sr_model_set_tap(sr_model* m, int op_index, float* device_dst, int64_t capacity);
 /* output shape for an input of [B,H,W,C]. */
 int  sr_model_output_shape(sr_model* m, int B, int H, int W, int C, int64_t out_shape[4]);
@@ -161,6 +163,12 @@ int  sr_ssim(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int
 /* mean squared error over all elements -> out f32 [1] (Keras loss="mean_squared_error",
  * SRCNN_model.py:59). */
 int  sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream);
+/* Pieces of the ESRGAN generator loss (ESRGAN_model.py:433-473; _train_step :511-523, evaluate :812-826): a, b f32 [B,H,W,C] device.
+ * sr_l1: mean |a - b| over n elements (_pixel_loss).  sr_spectral_l1: mean | |F(a)| - |F(b)| | with tf.signal.fft2d's axes, the
+ * INNERMOST two of NHWC = (W, C) (_spectral_loss; C must be 3).  Both write one float.  The adversarial term is a [B,1] vector
+ * (host arithmetic), the perceptual term is sr_mse on two SR_MODEL_VGG19_FEATURES outputs. */
+int  sr_l1(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream);
+int  sr_spectral_l1(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float* out1, void* stream);
 /* add_padding + sliding-window extraction (SRCNN_model.py:127-162, EDSR_model.py:201-223,
  * ESRGAN_model.py:883-901, VGG16_model.py:216-239): img f32 [H,W,C] (unpadded), reflect padding
  * bottom/right computed from (patch,stride); out [P,patch,patch,C] of out_dtype, each value

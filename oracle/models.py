@@ -299,6 +299,62 @@ def esrgan_g_forward(x, w, scale=2, num_rrdb=23, dtype=np.float32, attention=Tru
     return q(y) if bf16_output else y
 
 
+DISC_STRIDES = [1, 2, 1, 2, 1, 2]
+
+
+def discriminator_forward(x, w, u=None, training=False, dtype=np.float32):
+    """ESRGAN_model.py:347-377: six SpectralNormalization(Conv2D 3x3 SAME, strides 1,2,1,2,1,2) + LeakyReLU(0.2), GAP,
+    SN(Dense 256) + LeakyReLU, SN(Dense 1, sigmoid).  x in [-1,1], returns probabilities [B,1].
+    training=False (evaluate, :810-812): the stored kernels are used as they are.  training=True needs `u` ({layer: [1,Cout]}):
+    every wrapper renormalises its kernel in place first -- returns (probabilities, new weights, new u)."""
+    names = [f"disc_conv{i}" for i in range(1, 7)] + ["disc_dense1", "disc_output"]
+    if training:
+        w, u = dict(w), dict(u)
+        for n in names:
+            k, nu = ops.spectral_normalize(w[n][0], u[n])
+            w[n], u[n] = (k, w[n][1]), nu
+    h = np.asarray(x, dtype=dtype)
+    for i, st in enumerate(DISC_STRIDES):
+        h = ops.conv2d(h, *w[f"disc_conv{i + 1}"], stride=st, act="lrelu", dtype=dtype)
+    g = h.mean(axis=(1, 2), dtype=dtype)
+    g = ops.dense(g, *w["disc_dense1"], act="lrelu", dtype=dtype)
+    p = ops.dense(g, *w["disc_output"], act="sigmoid", dtype=dtype)
+    return (p, w, u) if training else p
+
+
+def vgg19_extractor_layers():
+    """ESRGAN_model.py:379-399: keras VGG19 (no top) cut at block5_conv4."""
+    L = vgg_base_layers(VGG19_CFG)
+    return L[:[n for n, _ in L].index("block5_conv4") + 1]
+
+
+def vgg19_features(x_pre, w, dtype=np.float32):
+    """x_pre: the preprocessed image (ops.vgg19_preprocess).  Output: block5_conv4 after its ReLU, [B, H/16, W/16, 512]."""
+    x = np.asarray(x_pre, dtype=dtype)
+    for blk, n, _ in VGG19_CFG:
+        for k in range(1, n + 1):
+            x = ops.conv2d(x, *w[f"block{blk}_conv{k}"], act="relu", dtype=dtype)
+            if (blk, k) == (5, 4):
+                return x
+        x = ops.maxpool2x2(x)
+    return x
+
+
+def generator_loss(hr_real, hr_fake, wd, wv, dtype=np.float32):
+    """The generator loss of ESRGAN._train_step / evaluate (ESRGAN_model.py:511-523, :812-826) for given generator output:
+    BCE(1, D(fake)) + 1.0 * perceptual + 100.0 * L1 + 1.0 * spectral; D and VGG19 run with training=False.
+    -> (g_loss, {'adversarial', 'perceptual', 'pixel', 'spectral'})."""
+    d_fake = discriminator_forward(hr_fake, wd, training=False, dtype=dtype)
+    adv = ops.binary_crossentropy_mean(np.ones_like(d_fake), d_fake)
+    fr = vgg19_features(ops.vgg19_preprocess(hr_real), wv, dtype=dtype)
+    ff = vgg19_features(ops.vgg19_preprocess(hr_fake), wv, dtype=dtype)
+    perc = float(np.mean((np.asarray(fr, np.float64) - np.asarray(ff, np.float64)) ** 2))
+    pix = ops.pixel_loss(hr_real, hr_fake)
+    spec = ops.spectral_loss(hr_real, hr_fake)
+    parts = {"adversarial": adv, "perceptual": perc, "pixel": pix, "spectral": spec}
+    return adv + 1.0 * perc + 100.0 * pix + 1.0 * spec, parts
+
+
 def vgg16_features(x, w, cfg=VGG16_CFG, dtype=np.float32):
     for blk, n, _ in cfg:
         for k in range(1, n + 1):

@@ -489,6 +489,57 @@ def ssim_naive(a, b, max_val=1.0):
 
 
 # --------------------------------------------------------------------------------------
+# ESRGAN losses (ESRGAN_model.py:401-473) and their library semantics
+# --------------------------------------------------------------------------------------
+def l2_normalize(x, eps=1e-12):
+    """tf.math.l2_normalize over all elements: x / sqrt(max(sum(x^2), eps))."""
+    x = np.asarray(x, np.float64)
+    return x / np.sqrt(max(float(np.sum(x * x)), eps))
+
+
+def spectral_normalize(kernel, u, power_iterations=1):
+    """tfa.layers.SpectralNormalization.normalize_weights (SURVEY.md A.6): w = reshape(kernel, [-1, Cout]); v = l2n(u w^T);
+    u = l2n(v w); sigma = v w u^T; returns (kernel / sigma, new u).  The reference applies it IN PLACE to the stored kernel on every
+    training=True call; with training=False the stored kernel is used as it is."""
+    k = np.asarray(kernel, np.float64)
+    w = k.reshape(-1, k.shape[-1])
+    u = np.asarray(u, np.float64).reshape(1, -1)
+    for _ in range(power_iterations):
+        v = l2_normalize(u @ w.T)
+        u = l2_normalize(v @ w)
+    sigma = float((v @ w @ u.T).item())
+    return (k / sigma).astype(np.asarray(kernel).dtype), u.astype(np.float32)
+
+
+def binary_crossentropy_mean(y_true, p, eps=1e-7):
+    """mean(keras.backend.binary_crossentropy(y_true, p)) on probabilities (ESRGAN_model.py:447-459): p clipped to
+    [eps, 1-eps], -(t log(p + eps) + (1 - t) log(1 - p + eps))."""
+    p = np.clip(np.asarray(p, np.float64), eps, 1.0 - eps)
+    t = np.asarray(y_true, np.float64)
+    return float(np.mean(-(t * np.log(p + eps) + (1.0 - t) * np.log(1.0 - p + eps))))
+
+
+def pixel_loss(a, b):
+    """ESRGAN_model.py:433-445: mean |hr_real - hr_fake|."""
+    return float(np.mean(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def spectral_loss(a, b):
+    """ESRGAN_model.py:461-473: tf.signal.fft2d transforms the INNERMOST two axes -- for NHWC batches that is (W, C), not (H, W)
+     -- then mean | |F(a)| - |F(b)| |."""
+    fa = np.abs(np.fft.fft2(np.asarray(a, np.float64), axes=(-2, -1)))
+    fb = np.abs(np.fft.fft2(np.asarray(b, np.float64), axes=(-2, -1)))
+    return float(np.mean(np.abs(fa - fb)))
+
+
+def vgg19_preprocess(x):
+    """ESRGAN_model.py:401-408 + keras.applications.vgg19.preprocess_input (caffe mode): [-1,1] -> [0,255],
+    RGB -> BGR, minus the ImageNet channel means [103.939, 116.779, 123.68] (B, G, R), no scaling."""
+    x = (np.asarray(x, np.float64) + 1.0) * 127.5
+    return x[..., ::-1] - np.array([103.939, 116.779, 123.68])
+
+
+# --------------------------------------------------------------------------------------
 # Patch plumbing (loading_methods.py:6-26; SRCNN_model.py:127-188; EDSR_model.py:201-256;
 # ESRGAN_model.py:883-921; VGG16_model.py:216-239)
 # --------------------------------------------------------------------------------------

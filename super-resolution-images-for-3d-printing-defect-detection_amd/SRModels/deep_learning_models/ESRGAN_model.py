@@ -3,8 +3,11 @@
 
 Generator (ESRGAN_model.py:303-345): conv3->64, NB x RRDB (3 dense blocks of 5 convs, residual scale 0.2),
 trunk conv + skip, SelfAttention, log2(scale) x (conv64->256, depth_to_space, LeakyReLU 0.2,
-SelfAttention after the first), conv64 ReLU, conv->3 tanh.  The discriminator, VGG19 perceptual net and
-the GAN training loop (_train_step :475-533) are the next row and are not built here.
+SelfAttention after the first), conv64 ReLU, conv->3 tanh.
+Discriminator (:347-377) and VGG19 perceptual extractor (:379-408) exist as inference graphs: together with the loss kernels
+(pixel L1, FFT-(W,C) spectral L1, MSE of VGG19 features; BCE on the [B,1] discriminator output) they give the generator loss that
+`evaluate` reports as avg_g_loss (:782-856).  The GAN training loop itself (_train_step :475-533: backward passes, spectral-norm
+updates, Adam) is the next row and is not built.
 """
 import os
 
@@ -46,9 +49,60 @@ class ESRGAN(DeviceModelMixin):
             print(f"- Generator loaded from: {generator_pretrained_path}")
         else:
             self._random_init(seed=3000)
+        self._d_path = discriminator_pretrained_path if from_trained else None
+        self.d_weights = self.vgg_weights = None
+
+    # ------------------------------------------------------------------ discriminator / VGG19 (inference graphs, built on first use)
+    def _ensure_loss_networks(self):
+        from sr355.runtime import Model
+        from sr355.weights import init_weights
+        if self.discriminator is None:
+            self.discriminator = Model("esrgan_d", compute_dtype="f32", ctx=self.ctx)
+            if self.d_weights is None:
+                if self._d_path is not None:
+                    if not os.path.exists(self._d_path):
+                        raise FileNotFoundError(f"Discriminator pretrained path does not exist: {self._d_path}")
+                    self.d_weights = load_pretrained(self._d_path)
+                else:
+                    self.d_weights = init_weights(self.discriminator.layer_shapes(), seed=5000)
+            self.discriminator.set_weights(self.d_weights)
+        if self.vgg_model is None:
+            self.vgg_model = Model("vgg19_features", compute_dtype="f32", ctx=self.ctx)
+            if self.vgg_weights is None:      # keras downloads ImageNet weights here (:388-392); offline: a seeded he-normal stand-in
+                self.vgg_weights = init_weights(self.vgg_model.layer_shapes(), scheme="he_normal", seed=6000)
+            self.vgg_model.set_weights(self.vgg_weights)
+
+    def set_loss_network_weights(self, discriminator=None, vgg19=None):
+        """{layer: (kernel, bias)} for the discriminator (disc_conv1..6, disc_dense1, disc_output: the stored, already spectrally
+        normalised kernels) and / or the VGG19 extractor (block1_conv1 .. block5_conv4)."""
+        if discriminator is not None:
+            self.d_weights = {n: (np.asarray(k, np.float32), np.asarray(b, np.float32)) for n, (k, b) in discriminator.items()}
+            self.discriminator = None
+        if vgg19 is not None:
+            self.vgg_weights = {n: (np.asarray(k, np.float32), np.asarray(b, np.float32)) for n, (k, b) in vgg19.items()}
+            self.vgg_model = None
+
+    def generator_loss(self, hr_real, hr_fake):
+        """g_loss of _train_step / evaluate for given generator output (ESRGAN_model.py:511-523, :812-826), on the device:
+        BCE(1, D(fake)) + 1.0 * MSE(VGG19(real), VGG19(fake)) + 100.0 * mean|real - fake| + 1.0 * spectral.
+        hr_real, hr_fake: [B,H,W,3] in [-1,1] (NumPy or device tensors).  -> (g_loss float, parts dict)."""
+        self._ensure_loss_networks()
+        real = self.ctx.to_device(hr_real, torch.float32) if not isinstance(hr_real, torch.Tensor) else hr_real.to(torch.float32).contiguous()
+        fake = self.ctx.to_device(hr_fake, torch.float32) if not isinstance(hr_fake, torch.Tensor) else hr_fake.to(torch.float32).contiguous()
+        d_fake = self.discriminator.forward(fake).cpu().numpy().astype(np.float64)
+        eps = 1e-7                                            # keras.backend.binary_crossentropy on probabilities (SURVEY.md A.7)
+        p = np.clip(d_fake, eps, 1.0 - eps)
+        adv = float(np.mean(-np.log(p + eps)))                # target = ones
+        perc = float(self.ctx.mse(self.vgg_model.forward(real), self.vgg_model.forward(fake)).item())
+        pix = float(self.ctx.l1(real, fake).item())
+        spec = float(self.ctx.spectral_l1(real, fake).item())
+        parts = {"adversarial": adv, "perceptual": perc, "pixel": pix, "spectral": spec}
+        return adv + 1.0 * perc + 100.0 * pix + 1.0 * spec, parts
 
     def fit(self, *args, **kwargs):
-        raise NotImplementedError("ESRGAN adversarial training is the next row (SURVEY.md 8f-1), not built yet")
+        raise NotImplementedError("ESRGAN adversarial training (_train_step: backward passes, spectral-norm updates, Adam) is the next row "
+                                  "(SURVEY.md 8f-1); its forward halves -- discriminator, VGG19 extractor, the four loss terms -- are "
+                                  "built: see generator_loss()")
 
     def generate(self, lr_batch):
         """generator(lr, training=False) on a [-1,1] batch (ESRGAN_model.py:810); NumPy or device tensor."""
@@ -57,24 +111,26 @@ class ESRGAN(DeviceModelMixin):
         return self.generator.predict(lr_batch, batch_size=64)
 
     def evaluate(self, test_dataset):
-        """PSNR/SSIM part of ESRGAN.evaluate (ESRGAN_model.py:782-856): iterable of ([-1,1] LR batch, [-1,1] HR batch);
-        mean of per-batch means (the reference's weighting, last partial batch included).  avg_g_loss needs the
-        discriminator/VGG19 losses of the training row and is reported as None."""
+        """ESRGAN.evaluate (ESRGAN_model.py:782-856): iterable of ([-1,1] LR batch, [-1,1] HR batch); per batch the generator
+        loss (same formula as training, discriminator and VGG19 at inference) and the means of PSNR / SSIM; the three results are
+        means of the per-batch values (the reference's weighting, last partial batch included)."""
         if not self.trained:
             raise RuntimeError("Model has not been trained.")
-        tp = ts = 0.0
+        tp = ts = tg = 0.0
         nb = 0
         for lr_batch, hr_batch in test_dataset:
             gen = self.ctx.to_device(self.generate(np.asarray(lr_batch, np.float32)))
             real = self.ctx.to_device(np.asarray(hr_batch, np.float32))
+            tg += self.generator_loss(real, gen)[0]
             g01, r01 = (gen + 1.0) / 2.0, (real + 1.0) / 2.0
             tp += float(self.ctx.psnr(r01, g01).mean().item())
             ts += float(self.ctx.ssim(r01, g01).mean().item())
             nb += 1
-        metrics = {"avg_psnr": tp / nb, "avg_ssim": ts / nb, "avg_g_loss": None}
+        metrics = {"avg_psnr": tp / nb, "avg_ssim": ts / nb, "avg_g_loss": tg / nb}
         print("Evaluation Results:")
         print(f"  Average PSNR: {metrics['avg_psnr']:.4f}")
         print(f"  Average SSIM: {metrics['avg_ssim']:.4f}")
+        print(f"  Average G Loss: {metrics['avg_g_loss']:.4f}")
         return metrics
 
     def super_resolve_image(self, lr_img, patch_size_lr=48, stride=24, batch_size=16):

@@ -87,7 +87,7 @@ struct Param {
     int64_t count() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
 };
 struct Ref { int buf = -1; int coff = 0; };        // buf: >=0 internal, -1 none, -2 caller's y
-enum OpKind { OP_CONVERT, OP_CONV, OP_ATTN, OP_POOL, OP_GAP, OP_DENSE, OP_TOBLK };
+enum OpKind { OP_CONVERT, OP_CONV, OP_ATTN, OP_POOL, OP_GAP, OP_DENSE, OP_TOBLK, OP_SUBSAMPLE, OP_PREPROC };
 struct Op {
     OpKind kind = OP_CONV;
     Ref in, out, skip1, skip2;
@@ -96,7 +96,7 @@ struct Op {
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
     int chain = -1, chain_pos = 0;                  // conv: member (first / second) of m->chains[chain]
 };
-struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h)
+struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs)
 struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
 struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; };
 // two consecutive convs of a dense block that run as ONE kernel when the shape allows (dense_fused.hip): ops[first], ops[first + 1]
@@ -116,7 +116,7 @@ struct sr_model {
     std::vector<void*> bufp;
     std::vector<float*> dense_dev;    // per param index (dense kernels / biases on device), else nullptr
     std::vector<Op> ops;
-    int in_C = 3, out_C = 3, out_mul = 1; bool out_vec = false;
+    int in_C = 3, out_C = 3, out_mul = 1, out_shift = 0; bool out_vec = false;
     bool finalized = false;
     std::vector<size_t> bufcap;       // bytes currently allocated per workspace buffer (grow-only)
     struct Tap { float* dst; int64_t cap; };
@@ -330,7 +330,71 @@ int build_vgg16(sr_model* m) {
     return SR_OK;
 }
 
-inline void buf_hw(const BufSpec& b, int H, int W, int* h, int* w) { *h = (H * b.mul) >> b.shift; *w = (W * b.mul) >> b.shift; }
+// ESRGAN discriminator, inference graph (ESRGAN_model.py:347-377 with training=False, as ESRGAN.evaluate runs it :810-812): six 3x3
+// SAME convs with strides 1,2,1,2,1,2 + LeakyReLU(0.2), GAP, Dense 256 + LeakyReLU, Dense 1 sigmoid.  The SpectralNormalization
+// wrappers only act when training (they renormalise the stored kernel in place): at inference the stored kernel is the
+// layer.  A stride-2 SAME conv = the stride-1 conv (LeakyReLU fused: elementwise) + a pick of every second position (imgops.hip).
+int build_discriminator(sr_model* m) {
+    Builder b{m};
+    m->in_C = 3; m->out_C = 1; m->out_vec = true;
+    const int x0 = b.buf(b.E());
+    m->bufs[x0].Cbuf = b.E();
+    Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
+    static const int filt[6] = {64, 64, 64, 128, 128, 256}, strd[6] = {1, 2, 1, 2, 1, 2};
+    int cur = x0, cin = 3, halv = 0;
+    for (int i = 0; i < 6; ++i) {
+        const int o = b.buf(filt[i]);
+        m->bufs[o].cshift = halv;
+        b.conv("disc_conv" + std::to_string(i + 1), 3, cin, filt[i], {cur, 0}, {o, 0}, SR_ACT_LRELU);
+        cur = o; cin = filt[i];
+        if (strd[i] == 2) {
+            ++halv;
+            const int s2 = b.buf(filt[i]);
+            m->bufs[s2].cshift = halv;
+            Op sp; sp.kind = OP_SUBSAMPLE; sp.in = {cur, 0}; sp.out = {s2, 0}; m->ops.push_back(sp);
+            cur = s2;
+        }
+    }
+    const int g = b.vecbuf(256), d1 = b.vecbuf(256);
+    { Op o; o.kind = OP_GAP; o.in = {cur, 0}; o.out = {g, 0}; m->ops.push_back(o); }
+    b.add_layer_params("disc_dense1", {256, 256});
+    { Op o; o.kind = OP_DENSE; o.in = {g, 0}; o.out = {d1, 0}; o.In = 256; o.Out = 256; o.act = SR_ACT_LRELU;
+      o.dw = m->find_param("disc_dense1", SR_WEIGHT_KERNEL); o.db = m->find_param("disc_dense1", SR_WEIGHT_BIAS); m->ops.push_back(o); }
+    b.add_layer_params("disc_output", {256, 1});
+    { Op o; o.kind = OP_DENSE; o.in = {d1, 0}; o.out = {-2, 0}; o.In = 256; o.Out = 1; o.act = 101;
+      o.dw = m->find_param("disc_output", SR_WEIGHT_KERNEL); o.db = m->find_param("disc_output", SR_WEIGHT_BIAS); m->ops.push_back(o); }
+    return SR_OK;
+}
+
+// VGG19 perceptual-feature extractor (ESRGAN_model.py:379-408): caffe-mode preprocessing of a [-1,1] image, then keras VGG19 without
+// top up to block5_conv4 (ReLU included) -> [B, H/16, W/16, 512].
+int build_vgg19_features(sr_model* m) {
+    Builder b{m};
+    m->in_C = 3; m->out_C = 512; m->out_mul = 1; m->out_shift = 4;
+    static const int cfg[5][2] = {{2, 64}, {2, 128}, {4, 256}, {4, 512}, {4, 512}};
+    const int x0 = b.buf(b.E());
+    m->bufs[x0].Cbuf = b.E();
+    Op pp; pp.kind = OP_PREPROC; pp.out = {x0, 0}; m->ops.push_back(pp);
+    int cur = x0, cin = 3;
+    for (int blk = 0; blk < 5; ++blk) {
+        for (int k = 0; k < cfg[blk][0]; ++k) {
+            const bool last = blk == 4 && k == cfg[blk][0] - 1;
+            const int o = last ? -2 : b.buf(cfg[blk][1], 1, blk);
+            b.conv("block" + std::to_string(blk + 1) + "_conv" + std::to_string(k + 1), 3, cin, cfg[blk][1], {cur, 0}, {o, 0}, SR_ACT_RELU);
+            cur = o; cin = cfg[blk][1];
+        }
+        if (blk == 4) break;
+        const int pb = b.buf(cin, 1, blk + 1);
+        Op p; p.kind = OP_POOL; p.in = {cur, 0}; p.out = {pb, 0}; m->ops.push_back(p);
+        cur = pb;
+    }
+    return SR_OK;
+}
+
+inline void buf_hw(const BufSpec& b, int H, int W, int* h, int* w) {
+    *h = (H * b.mul) >> b.shift; *w = (W * b.mul) >> b.shift;
+    for (int i = 0; i < b.cshift; ++i) { *h = (*h + 1) / 2; *w = (*w + 1) / 2; }
+}
 
 // Workspaces grow on demand and are never shrunk.  Every buffer is [pixels][Cbuf]: the position of the pad
 // channels inside a pixel does not depend on (B,H,W), so zeroing them once at allocation stays valid for every
@@ -498,6 +562,8 @@ int sr_model_create(sr_ctx* ctx, int kind, const sr_model_cfg* cfg, sr_model** o
         case SR_MODEL_EDSR: rc = build_edsr(m.get()); break;
         case SR_MODEL_ESRGAN_G: rc = build_esrgan(m.get()); break;
         case SR_MODEL_VGG16: rc = build_vgg16(m.get()); break;
+        case SR_MODEL_ESRGAN_D: rc = build_discriminator(m.get()); break;
+        case SR_MODEL_VGG19_FEATURES: rc = build_vgg19_features(m.get()); break;
         default: return ctx->fail(SR_ERR_INVALID, "unknown model kind");
     }
     if (rc) return rc;
@@ -526,12 +592,14 @@ int sr_model_release_workspace(sr_model* m) {
 }
 
 // ---- diagnostics: the op list and per-op output taps (stage-by-stage parity traces in tests/) ------------------------
-static void op_out_view(const sr_model* m, const Op& op, int* C, int* mul, int* shift) {
+static void op_out_view(const sr_model* m, const Op& op, int* C, int* mul, int* shift, int* cshift = nullptr) {
     *C = 0; *mul = 1; *shift = 0;
+    if (cshift) *cshift = 0;
     if (op.out.buf < 0) return;
     const BufSpec& b = m->bufs[op.out.buf];
     if (b.vec) return;
     *mul = b.mul; *shift = b.shift;
+    if (cshift) *cshift = b.cshift;
     if (op.kind == OP_CONV) { const ConvSpec& cs = m->convs[op.conv]; *C = cs.Cout / (op.d2s * op.d2s); }
     else if (op.kind == OP_ATTN) *C = 32;
     else if (op.kind == OP_TOBLK) *C = 64;
@@ -540,20 +608,21 @@ static void op_out_view(const sr_model* m, const Op& op, int* C, int* mul, int* 
 
 int sr_model_num_ops(sr_model* m) { return m ? (int)m->ops.size() : SR_ERR_INVALID; }
 
-int sr_model_op_info(sr_model* m, int index, const char** name, int* channels, int* mul, int* shift) {
+int sr_model_op_info(sr_model* m, int index, const char** name, int* channels, int* mul, int* shift, int* ceil_halvings) {
     if (!m || index < 0 || index >= (int)m->ops.size()) return SR_ERR_INVALID;
     if (m->op_names.size() != m->ops.size()) {
         m->op_names.clear();
-        static const char* kinds[] = {"convert", "conv", "attention", "maxpool", "gap", "dense", "to_blocked"};
+        static const char* kinds[] = {"convert", "conv", "attention", "maxpool", "gap", "dense", "to_blocked", "stride2_pick", "vgg_preprocess"};
         for (const Op& op : m->ops)
             m->op_names.push_back(op.kind == OP_CONV ? m->convs[op.conv].parts[0].name : std::string(kinds[op.kind]));
     }
-    int C, mu, sh;
-    op_out_view(m, m->ops[index], &C, &mu, &sh);
+    int C, mu, sh, cs;
+    op_out_view(m, m->ops[index], &C, &mu, &sh, &cs);
     if (name) *name = m->op_names[index].c_str();
     if (channels) *channels = C;
     if (mul) *mul = mu;
     if (shift) *shift = sh;
+    if (ceil_halvings) *ceil_halvings = cs;
     return SR_OK;
 }
 
@@ -648,7 +717,7 @@ int sr_model_output_shape(sr_model* m, int B, int H, int W, int C, int64_t out_s
     if (!m || !out_shape) return SR_ERR_INVALID;
     (void)C;
     if (m->out_vec) { out_shape[0] = B; out_shape[1] = m->out_C; out_shape[2] = 1; out_shape[3] = 1; }
-    else { out_shape[0] = B; out_shape[1] = (int64_t)H * m->out_mul; out_shape[2] = (int64_t)W * m->out_mul; out_shape[3] = m->out_C; }
+    else { out_shape[0] = B; out_shape[1] = ((int64_t)H * m->out_mul) >> m->out_shift; out_shape[2] = ((int64_t)W * m->out_mul) >> m->out_shift; out_shape[3] = m->out_C; }
     return SR_OK;
 }
 
@@ -668,6 +737,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
     sr_model_output_shape(m, B, H, W, C, os);
     if (y_capacity < os[0] * os[1] * os[2] * os[3]) return ctx->fail(SR_ERR_CAPACITY, "output buffer too small");
     if (m->kind == SR_MODEL_VGG16 && (H < 32 || W < 32)) return ctx->fail(SR_ERR_INVALID, "VGG16 needs H,W >= 32");
+    if (m->kind == SR_MODEL_VGG19_FEATURES && (H < 16 || W < 16)) return ctx->fail(SR_ERR_INVALID, "VGG19 features need H,W >= 16");
     int rc = ensure_workspace(m, B, H, W, st);
     if (rc) return rc;
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
@@ -721,6 +791,13 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 rc = attention_launch(ctx, T, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, /*q=g*/ 8, /*k=f*/ 0, /*v=h*/ 16, B, h * w,
                                       m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, 0, st);
                 break;
+            case OP_SUBSAMPLE:
+                rc = subsample2_launch(ctx, T, m->bufp[op.in.buf], B, h, w, m->bufs[op.in.buf].C, m->bufs[op.in.buf].Cbuf, m->bufp[op.out.buf],
+                                       m->bufs[op.out.buf].Cbuf, st);
+                break;
+            case OP_PREPROC:
+                rc = vgg_preproc_launch(ctx, x, io_dtype, (int64_t)B * H * W, m->bufp[op.out.buf], T, m->bufs[op.out.buf].Cbuf, st);
+                break;
             case OP_TOBLK:
                 rc = nhwc_to_blocked_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.out.buf],
                                             m->bufs[op.out.buf].Cbuf, op.out.coff, st);
@@ -750,7 +827,8 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
             if (it != m->taps.end()) {
                 int C_, mu, sh;
                 op_out_view(m, op, &C_, &mu, &sh);
-                const int th = (H * mu) >> sh, tw = (W * mu) >> sh;
+                int th, tw;
+                buf_hw(m->bufs[op.out.buf], H, W, &th, &tw);
                 if (it->second.cap < (int64_t)B * th * tw * C_) return ctx->fail(SR_ERR_CAPACITY, "tap buffer too small");
                 const BufSpec& ob = m->bufs[op.out.buf];
                 rc = tap_copy_launch(ctx, m->bufp[op.out.buf], T, ob.blk, ob.Cbuf, op.out.coff, B, th, tw, C_, it->second.dst, st);
@@ -873,6 +951,20 @@ int sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, vo
     if (!ctx) return SR_ERR_INVALID;
     if (!a || !b || !out1) return ctx->fail(SR_ERR_INVALID, "null tensor");
     return mse_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), n, out1, static_cast<hipStream_t>(stream));
+}
+
+int sr_l1(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !b || !out1) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return l1_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), n, out1, static_cast<hipStream_t>(stream));
+}
+
+int sr_spectral_l1(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float* out1, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !b || !out1) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return spectral_l1_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), B, H, W, C, out1, static_cast<hipStream_t>(stream));
 }
 
 int sr_extract_patches(sr_ctx* ctx, const float* img, int H, int W, int C, int patch, int stride, float mul, float add, int out_dtype,

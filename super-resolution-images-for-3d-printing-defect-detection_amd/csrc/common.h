@@ -159,11 +159,15 @@ int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, i
 int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y,
                     int64_t y_cs, hipStream_t st);
 int gap_launch(sr_ctx* ctx, int dtype, const void* x, int B, int HW, int C, int64_t x_cs, float* y, hipStream_t st);
-// y[b,o] = act(sum_i x[b,i] w[i,o] + bias[o]); act: SR_ACT_* or 100 = softmax over o.  fp32 in/out.
+// y[b,o] = act(sum_i x[b,i] w[i,o] + bias[o]); act: SR_ACT_LINEAR / _RELU / _LRELU, 100 = softmax over o, 101 = sigmoid.  fp32 in/out.
 int dense_launch(sr_ctx* ctx, const float* x, const float* w, const float* bias, int B, int In, int Out, int act,
                  float* y, int y_dtype, void* y_typed, hipStream_t st);
 int bicubic_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW,
                    void* y, int out_dtype, int64_t y_cs, hipStream_t st);
+int subsample2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs, hipStream_t st);
+int vgg_preproc_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, void* y, int out_dtype, int Cp, hipStream_t st);
+int l1_launch(sr_ctx* ctx, const float* a, const float* b, int64_t n, float* out, hipStream_t st);
+int spectral_l1_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float* out, hipStream_t st);
 int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, int interp, void* y, hipStream_t st);
 int psnr_launch(sr_ctx* ctx, const float* a, const float* b, int B, int64_t n_per_image, float max_val, float* out,
                 hipStream_t st);

@@ -73,6 +73,8 @@ __global__ void dense_kernel(const float* x, const float* w, const float* bias, 
         for (int i = 0; i < In; ++i) s += xb[i] * w[(int64_t)i * Out + o];
         s += bias ? bias[o] : 0.f;
         if (act == SR_ACT_RELU) s = fmaxf(s, 0.f);
+        else if (act == SR_ACT_LRELU) s = s > 0.f ? s : 0.2f * s;
+        else if (act == 101) s = 1.f / (1.f + expf(-s));             // sigmoid (discriminator output, ESRGAN_model.py:373)
         logits[o] = s;
     }
     __syncthreads();
@@ -810,6 +812,139 @@ int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, in
     else
         hipLaunchKernelGGL(resize_apply_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const uint8_t*>(x), B, H, W, C, outH, outW, TX, TY, ix, iwx, iy, iwy,
                            static_cast<uint8_t*>(y));
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pieces of the ESRGAN generator loss (ESRGAN_model.py:401-473) and of its discriminator / VGG19 graphs
+// ------------------------------------------------------------------------------------------------
+// Keras Conv2D(strides=2, padding="same") == the stride-1 SAME conv sampled at every second position: TF pads
+// total = max((ceil(n/2)-1)*2 + 3 - n, 0) with the smaller half in FRONT, so for even n output i sits on input 2i+1 (pad 0 / 1) and
+// for odd n on input 2i (pad 1 / 1).  (the discriminator's maps 48 -> 24 -> 12 -> 6.)
+__global__ void subsample2_kernel(const void* x, int dtype, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs, int oH, int oW) {
+    const int64_t n = (int64_t)B * oH * oW * C;
+    const int offy = (H & 1) ? 0 : 1, offx = (W & 1) ? 0 : 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % oW); t /= oW;
+        const int oy = (int)(t % oH);
+        const int64_t b = t / oH;
+        const int64_t src = ((b * H + 2 * oy + offy) * W + 2 * ox + offx) * x_cs + c, dst = ((b * oH + oy) * oW + ox) * y_cs + c;
+        if (dtype == SR_DTYPE_BF16) static_cast<bf16_t*>(y)[dst] = static_cast<const bf16_t*>(x)[src];
+        else static_cast<float*>(y)[dst] = static_cast<const float*>(x)[src];
+    }
+}
+
+int subsample2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs, hipStream_t st) {
+    const int oH = (H + 1) / 2, oW = (W + 1) / 2;
+    const int64_t n = (int64_t)B * oH * oW * C;
+    if (n <= 0) return ctx->fail(SR_ERR_INVALID, "stride-2 conv: empty tensor");
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, dtype, B, H, W, C, x_cs, y, y_cs, oH, oW);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+// _preprocess_vgg_input (ESRGAN_model.py:401-408): [-1,1] RGB -> (x+1)*127.5 -> BGR - ImageNet means (caffe mode)
+__global__ void vgg_preproc_kernel(const void* x, int in_dtype, int64_t npix, void* y, int out_dtype, int Cp) {
+    const int64_t n = npix * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const int64_t p = i / Cp;
+        float v = 0.f;
+        if (c < 3) {
+            const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+            v = (ld_dt(x, p * 3 + (2 - c), in_dtype) + 1.f) * 127.5f - mean;
+        }
+        st_dt(y, i, v, out_dtype);
+    }
+}
+
+int vgg_preproc_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, void* y, int out_dtype, int Cp, hipStream_t st) {
+    if (npix <= 0) return SR_OK;
+    hipLaunchKernelGGL(vgg_preproc_kernel, dim3(grid_for(npix * Cp)), dim3(256), 0, st, x, in_dtype, npix, y, out_dtype, Cp);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+__global__ void absdiff_partial_kernel(const float* a, const float* b, int64_t n, float* partial) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += fabsf(a[i] - b[i]);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+int l1_launch(sr_ctx* ctx, const float* a, const float* b, int64_t n, float* out, hipStream_t st) {
+    if (n <= 0) return ctx->fail(SR_ERR_INVALID, "l1: empty tensor");
+    const int nblk = (int)grid_for(n) > 1024 ? 1024 : (int)grid_for(n);
+    float* partial;
+    int rc = reduce_scratch(ctx, (size_t)nblk, &partial);
+    if (rc) return rc;
+    hipLaunchKernelGGL(absdiff_partial_kernel, dim3(nblk), dim3(256), 0, st, a, b, n, partial);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partial, nblk, (double)n, 1.f, 1, out);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+// _spectral_loss (ESRGAN_model.py:461-473): tf.signal.fft2d works on the innermost two axes -- (W, C) of an NHWC batch.
+// One workgroup per image row (b, h): the 3-point DFT over the channels per pixel, then for each of the W x 3 output bins the W-point
+// DFT by direct summation against a twiddle table (W is 48..192 here: a few hundred k MACs per row); sum | |F(a)| - |F(b)| |.
+__global__ void __launch_bounds__(256) spectral_wc_partial_kernel(const float* a, const float* b, int W, float* partial) {
+    extern __shared__ float sm[];
+    float* tw = sm;                       // [W][2]   cos, -sin of 2 pi k / W
+    float* ga = tw + 2 * W;               // [W][3][2] channel DFT of image a
+    float* gb = ga + 6 * W;
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const float* ra = a + row * W * 3;
+    const float* rb = b + row * W * 3;
+    for (int k = threadIdx.x; k < W; k += blockDim.x) {
+        double s, c;
+        sincospi(2.0 * (double)k / (double)W, &s, &c);
+        tw[2 * k] = (float)c; tw[2 * k + 1] = (float)(-s);
+        const float c3 = -0.5f, s3 = 0.86602540378443864676f;          // exp(-2 pi i / 3) = c3 - i s3
+        for (int im = 0; im < 2; ++im) {
+            const float* r = im ? rb : ra;
+            float* g = im ? gb : ga;
+            const float x0 = r[3 * k], x1 = r[3 * k + 1], x2 = r[3 * k + 2];
+            g[6 * k + 0] = x0 + x1 + x2;                  g[6 * k + 1] = 0.f;
+            g[6 * k + 2] = x0 + c3 * (x1 + x2);           g[6 * k + 3] = -s3 * (x1 - x2);     // v = 1: x1 e^{-2pi i/3} + x2 e^{-4pi i/3}
+            g[6 * k + 4] = x0 + c3 * (x1 + x2);           g[6 * k + 5] = s3 * (x1 - x2);      // v = 2: the conjugate for real input
+        }
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int o = threadIdx.x; o < 3 * W; o += blockDim.x) {
+        const int u = o / 3, v = o - 3 * u;
+        float are = 0.f, aim = 0.f, bre = 0.f, bim = 0.f;
+        int k = 0;                                     // (u * w) mod W, incrementally
+        for (int w = 0; w < W; ++w) {
+            const float tc = tw[2 * k], ts = tw[2 * k + 1];
+            const float gar = ga[6 * w + 2 * v], gai = ga[6 * w + 2 * v + 1], gbr = gb[6 * w + 2 * v], gbi = gb[6 * w + 2 * v + 1];
+            are += gar * tc - gai * ts; aim += gar * ts + gai * tc;
+            bre += gbr * tc - gbi * ts; bim += gbr * ts + gbi * tc;
+            k += u; if (k >= W) k -= W;
+        }
+        acc += fabsf(sqrtf(are * are + aim * aim) - sqrtf(bre * bre + bim * bim));
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[row] = acc;
+}
+
+int spectral_l1_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float* out, hipStream_t st) {
+    if (C != 3) return ctx->fail(SR_ERR_INVALID, "spectral loss: built for 3 channels (the FFT runs over the (W, C) axes)");
+    if (B <= 0 || H <= 0 || W <= 0 || W > 4096) return ctx->fail(SR_ERR_INVALID, "spectral loss: bad shape");
+    const int64_t rows = (int64_t)B * H;
+    float* partial;
+    int rc = reduce_scratch(ctx, (size_t)rows, &partial);
+    if (rc) return rc;
+    const size_t lds = sizeof(float) * (size_t)(2 * W + 12 * W);
+    auto kern = spectral_wc_partial_kernel;
+    if (lds > 48 * 1024) { if (int r2 = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return r2; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(256), lds, st, a, b, W, partial);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partial, (int)rows, (double)rows * W * 3, 1.f, 1, out);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }

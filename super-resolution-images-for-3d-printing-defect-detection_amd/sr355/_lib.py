@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libsr355.so")
 SR_OK = 0
 SR_ERR_INVALID, SR_ERR_HIP, SR_ERR_OOM, SR_ERR_STATE, SR_ERR_NAME, SR_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
 DTYPE_F32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2
-MODEL_SRCNN, MODEL_EDSR, MODEL_ESRGAN_G, MODEL_VGG16 = 0, 1, 2, 3
+MODEL_SRCNN, MODEL_EDSR, MODEL_ESRGAN_G, MODEL_VGG16, MODEL_ESRGAN_D, MODEL_VGG19_FEATURES = 0, 1, 2, 3, 4, 5
 ACT_LINEAR, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 WEIGHT_KERNEL, WEIGHT_BIAS = 0, 1
 
@@ -45,7 +45,7 @@ SIGNATURES = {
     "sr_model_destroy": (None, [_vp]),
     "sr_model_release_workspace": (_i, [_vp]),
     "sr_model_num_ops": (_i, [_vp]),
-    "sr_model_op_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "sr_model_op_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "sr_model_set_tap": (_i, [_vp, _i, _vp, _i64]),
     "sr_model_num_params": (_i, [_vp]),
     "sr_model_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i), _i64p, C.POINTER(_i)]),
@@ -60,6 +60,8 @@ SIGNATURES = {
     "sr_psnr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "sr_l1": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "sr_spectral_l1": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sr_extract_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i64, C.POINTER(_i), _vp]),
     "sr_overlap_add": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp]),
 }

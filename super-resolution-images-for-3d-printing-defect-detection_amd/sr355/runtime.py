@@ -211,6 +211,27 @@ class Context:
         self.check(self.lib.sr_mse(self.h, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), self.stream()))
         return out
 
+    def l1(self, a, b):
+        """mean |a - b| (ESRGAN _pixel_loss) -> [1] tensor."""
+        _check_tensor(self, a, "l1 input a")
+        _check_tensor(self, b, "l1 input b")
+        if a.shape != b.shape:
+            raise ValueError("l1 inputs must have the same shape")
+        out = self.empty((1,), torch.float32)
+        self.check(self.lib.sr_l1(self.h, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), self.stream()))
+        return out
+
+    def spectral_l1(self, a, b):
+        """mean | |fft2(a)| - |fft2(b)| | over the (W, C) axes of [B,H,W,3] tensors (ESRGAN _spectral_loss) -> [1] tensor."""
+        _check_tensor(self, a, "spectral input a")
+        _check_tensor(self, b, "spectral input b")
+        if a.shape != b.shape or a.dim() != 4:
+            raise ValueError("spectral loss inputs must be two [B,H,W,3] tensors of the same shape")
+        B, H, W, Cx = a.shape
+        out = self.empty((1,), torch.float32)
+        self.check(self.lib.sr_spectral_l1(self.h, a.data_ptr(), b.data_ptr(), B, H, W, Cx, out.data_ptr(), self.stream()))
+        return out
+
     def num_patches(self, H, W, C_, patch, stride):
         n = C.c_int()
         self.check(self.lib.sr_extract_patches(self.h, None, H, W, C_, patch, stride, 1.0, 0.0, L.DTYPE_F32, None, 0, C.byref(n), None))
@@ -238,7 +259,8 @@ class Context:
 class Model:
     """sr_model wrapper: build from the reference's setup_model() hyper-parameters, load Keras-named
     weights, run forward on device tensors."""
-    KINDS = {"srcnn": L.MODEL_SRCNN, "edsr": L.MODEL_EDSR, "esrgan_g": L.MODEL_ESRGAN_G, "vgg16": L.MODEL_VGG16}
+    KINDS = {"srcnn": L.MODEL_SRCNN, "edsr": L.MODEL_EDSR, "esrgan_g": L.MODEL_ESRGAN_G, "vgg16": L.MODEL_VGG16,
+             "esrgan_d": L.MODEL_ESRGAN_D, "vgg19_features": L.MODEL_VGG19_FEATURES}
 
     def __init__(self, kind, compute_dtype="f32", scale_factor=1, channels=3, num_blocks=0, num_filters=64,
                  growth_channels=32, res_scaling=0.1, num_classes=2, use_attention=True, ctx=None):
@@ -295,7 +317,7 @@ class Model:
     def output_shape(self, B, H, W, Cx):
         s = (C.c_int64 * 4)()
         self.ctx.check(self.ctx.lib.sr_model_output_shape(self.h, B, H, W, Cx, s))
-        return tuple(s) if self.kind != "vgg16" else (s[0], s[1])
+        return tuple(s) if self.kind not in ("vgg16", "esrgan_d") else (s[0], s[1])
 
     def forward(self, x, out=None):
         """x [B,H,W,C] device tensor (f32, or bf16 for a bf16 model) -> output tensor of the same dtype."""
@@ -320,14 +342,21 @@ class Model:
         self.ctx.check(self.ctx.lib.sr_model_release_workspace(self.h))
 
     def ops(self):
-        """[(name, channels, mul, shift)] per graph op: Keras layer name of a conv, else the op kind; the op's output is
-        [B, (H*mul)>>shift, (W*mul)>>shift, channels] (channels 0: no activation output)."""
+        """[(name, channels, mul, shift, ceil_halvings)] per graph op: Keras layer name of a conv, else the op kind; the op's output is
+        [B, h, w, channels] with h = (H*mul)>>shift, then ceil-halved ceil_halvings times (channels 0: no activation output)."""
         lib, out = self.ctx.lib, []
         for i in range(lib.sr_model_num_ops(self.h)):
-            name, ch, mul, sh = C.c_char_p(), C.c_int(), C.c_int(), C.c_int()
-            self.ctx.check(lib.sr_model_op_info(self.h, i, C.byref(name), C.byref(ch), C.byref(mul), C.byref(sh)))
-            out.append((name.value.decode(), ch.value, mul.value, sh.value))
+            name, ch, mul, sh, cs = C.c_char_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            self.ctx.check(lib.sr_model_op_info(self.h, i, C.byref(name), C.byref(ch), C.byref(mul), C.byref(sh), C.byref(cs)))
+            out.append((name.value.decode(), ch.value, mul.value, sh.value, cs.value))
         return out
+
+    @staticmethod
+    def _op_hw(op, H, W):
+        h, w = (H * op[2]) >> op[3], (W * op[2]) >> op[3]
+        for _ in range(op[4]):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        return h, w
 
     def forward_with_taps(self, x, names):
         """Diagnostic forward: -> (y, {name: fp32 NHWC tensor}) with the output of the LAST op called `name` for every name
@@ -342,8 +371,8 @@ class Model:
             idx[n] = hits[-1]
         try:
             for n, i in idx.items():
-                _, ch, mul, sh = ops[i]
-                t = self.ctx.empty((B, (H * mul) >> sh, (W * mul) >> sh, ch), torch.float32)
+                th, tw = self._op_hw(ops[i], H, W)
+                t = self.ctx.empty((B, th, tw, ops[i][1]), torch.float32)
                 self.ctx.check(self.ctx.lib.sr_model_set_tap(self.h, i, t.data_ptr(), t.numel()))
                 taps[n] = t
             y = self.forward(x)

@@ -6,7 +6,8 @@ the LAST forward of the probe.  Keys are bench.py's kernel names."""
 import csv, glob, json, sys
 
 NAMES = {"conv3_rows_kernel<1,": "conv_rows<bf16,k3,kg1,nt1>", "conv3_rows_kernel<2,": "conv_rows<bf16,k3,kg1,nt2>",
-         "conv3_rows_kernel<4,": "conv_rows<bf16,k3,kg1,nt4>"}
+         "conv3_rows_kernel<4,": "conv_rows<bf16,k3,kg1,nt4>",
+         "chain2_kernel<5,2,4,1,": "dense_tail_fused<bf16,conv4+conv5>", "chain2_kernel<3,2,2,0,": "dense_pair_fused<bf16>"}
 
 
 def load(d, counter):
@@ -28,7 +29,7 @@ for k in range(last - n_per_fwd + 1, last + 1):
         continue
     name, grid, fv = fetch[k]
     for pat, nm in NAMES.items():
-        if pat in name.replace(" ", "") or pat.replace(",", ", ") in name:
+        if pat in name.replace(" ", ""):
             if int(grid) > 0 and nm == "conv_rows<bf16,k3,kg1,nt2>" or nm != "conv_rows<bf16,k3,kg1,nt2>":
                 a = agg.setdefault(nm, [0, 0.0])
                 a[0] += 1
