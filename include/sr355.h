@@ -43,6 +43,9 @@ enum { SR_MODEL_SRCNN = 0, SR_MODEL_EDSR = 1, SR_MODEL_ESRGAN_G = 2, SR_MODEL_VG
        SR_MODEL_VGG19_FEATURES = 5 };  /* perceptual-loss extractor incl. preprocessing (ESRGAN_model.py:379-408): -> [B,H/16,W/16,512]     */
 enum { SR_ACT_LINEAR = 0, SR_ACT_RELU = 1, SR_ACT_LRELU = 2, SR_ACT_TANH = 3 };
 enum { SR_WEIGHT_KERNEL = 0, SR_WEIGHT_BIAS = 1 };
+/* sr_eltwise ops: out = alpha*a + beta*b | dy where y > 0 | dy (0.2 dy where y <= 0) | dy where 0 <= x <= 1 | alpha*a*b | dy*(1 - y^2) |
+ * clip(a, 0, 1) */
+enum { SR_ELT_AXPBY = 0, SR_ELT_RELU_BWD = 1, SR_ELT_LRELU_BWD = 2, SR_ELT_CLIP01_BWD = 3, SR_ELT_MUL = 4, SR_ELT_TANH_BWD = 5, SR_ELT_CLIP01 = 6 };
 
 /* Architecture hyper-parameters = the keyword arguments of the reference's setup_model():
  * SRCNN_model.py:23, EDSR_model.py:29, ESRGAN_model.py:108, VGG16_model.py:21. */
@@ -169,6 +172,17 @@ int  sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, v
  * (host arithmetic), the perceptual term is sr_mse on two SR_MODEL_VGG19_FEATURES outputs. */
 int  sr_l1(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream);
 int  sr_spectral_l1(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float* out1, void* stream);
+/* Backward-pass pieces of Keras model.fit (SRCNN_model.py:84-90, EDSR_model.py:164-170: loss = mean_squared_error, Adam) and of
+ * ESRGAN._train_step (ESRGAN_model.py:475-533).  fp32 device tensors, NHWC dense.
+ * sr_conv2d_wgrad: gradient of a Keras Conv2D(K x K, SAME, stride 1) kernel and bias: dw HWIO [K,K,Cin,Cout] = sum over pixels of
+ *   x[b, y+ky-p, x+kx-p, ci] * dy[b,y,x,co];  db [Cout] = sum of dy (NULL to skip).  The input gradient needs no entry point of its
+ *   own: it is sr_conv2d on dy with the kernel rotated by 180 degrees and its channel axes swapped.
+ * sr_eltwise: the element-wise halves of the chain rule (SR_ELT_*), a / b / out of n floats (b may be NULL for AXPBY with beta 0).
+ * sr_space_to_depth: the inverse of tf.nn.depth_to_space (DCR order): x [B,H*r,W*r,C] -> y [B,H,W,r*r*C] (its gradient). */
+int  sr_conv2d_wgrad(sr_ctx* ctx, const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, int K,
+                     float* dw_hwio, float* db, void* stream);
+int  sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, float beta, void* out, int64_t n, void* stream);
+int  sr_space_to_depth(sr_ctx* ctx, const void* x, int B, int H, int W, int C, int r, void* y, void* stream);
 /* add_padding + sliding-window extraction (SRCNN_model.py:127-162, EDSR_model.py:201-223,
  * ESRGAN_model.py:883-901, VGG16_model.py:216-239): img f32 [H,W,C] (unpadded), reflect padding
  * bottom/right computed from (patch,stride); out [P,patch,patch,C] of out_dtype, each value

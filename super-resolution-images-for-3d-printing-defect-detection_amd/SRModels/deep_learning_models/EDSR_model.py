@@ -34,14 +34,37 @@ class EDSR(DeviceModelMixin):
             num_filters = int(weights["conv2d"][0].shape[-1])
         self._make("edsr", self.compute_dtype, scale_factor=scale_factor, channels=channels, num_blocks=num_res_blocks,
                    num_filters=num_filters, res_scaling=res_scaling)
+        self.num_res_blocks, self.res_scaling, self.learning_rate = num_res_blocks, res_scaling, learning_rate
         if weights is not None:
             self.set_weights(weights)
             print(f"Loaded pretrained model from {pretrained_path}")
         else:
             self._random_init(seed=2000)
 
-    def fit(self, *args, **kwargs):
-        raise NotImplementedError("EDSR training is outside this round's hot path (SURVEY.md 8f row 4)")
+    def fit(self, X_train, Y_train, X_val, Y_val, batch_size=16, epochs=300, shuffle=True, verbose=True):
+        """Train the model (EDSR_model.py:127-176): Adam(lr, eps 1e-8, clipnorm 1.0), loss = mean_squared_error whatever `loss` said
+        at setup (reference quirk, :137), EarlyStopping(patience 5, restore_best_weights), ReduceLROnPlateau(0.5, patience 3, 1e-7).
+        Returns (history, epoch-time record, epoch-memory record)."""
+        if self.model is None:
+            raise ValueError("Model is not built yet.")
+        if self.compute_dtype not in ("f32", "float32"):
+            raise ValueError("training runs in fp32 (the reference's precision); build the model with compute_dtype='f32'")
+        from functools import partial
+        from sr355 import train as T
+        print("Training on GPU:", torch.cuda.get_device_name(self.ctx.torch_device))
+        opt = T.Adam(self.weights, learning_rate=self.learning_rate, epsilon=1e-8, clipnorm=1.0)
+        lg = partial(T.edsr_loss_and_grads, scale=self.scale_factor, num_res_blocks=self.num_res_blocks, res_scaling=self.res_scaling)
+        weights, history, tcb, mcb = T.fit(self.ctx, self.weights, lg, self._predict_with, opt, X_train, Y_train, X_val, Y_val,
+                                           batch_size=batch_size, epochs=epochs, es_patience=5, lr_patience=3, shuffle=shuffle, verbose=verbose)
+        self.set_weights(weights)
+        self.trained = True
+        return history, tcb, mcb
+
+    def _predict_with(self, ctx, weights, x):
+        if weights is not getattr(self, "_loaded_for_predict", None):
+            self.model.set_weights(weights)
+            self._loaded_for_predict = weights
+        return self.model.forward(x)
 
     def evaluate(self, X_test, Y_test):
         if not self.trained:

@@ -1,8 +1,8 @@
 """SRCNN on MI355X behind the reference's class surface (reference: deep_learning_models/SRCNN_model.py).
 
 Graph (SRCNN_model.py:48-53): conv9x9x96 ReLU -> conv1x1x32 ReLU -> conv5x5x3 linear, SAME, on a
-bicubic pre-upscaled image.  Forward, bicubic, patch plumbing and metrics are libsr355 kernels;
-`fit` (MSE/Adam training) is a later row of SURVEY.md section 8f.
+bicubic pre-upscaled image.  Forward, bicubic, patch plumbing and metrics are libsr355 kernels; `fit` (Keras model.fit with
+MSE / Adam / EarlyStopping / ReduceLROnPlateau, SRCNN_model.py:55-98) runs through sr355/train.py.
 """
 import os
 
@@ -37,8 +37,28 @@ class SRCNNModel(DeviceModelMixin):
             self._random_init(seed=1000)
         self.learning_rate = learning_rate
 
-    def fit(self, *args, **kwargs):
-        raise NotImplementedError("SRCNN training is outside this round's hot path (SURVEY.md 8f row 4)")
+    def fit(self, X_train, Y_train, X_val, Y_val, batch_size=16, epochs=50, shuffle=True, verbose=True):
+        """Trains the model (SRCNN_model.py:62-98): Adam(learning_rate), loss = mean_squared_error, metrics psnr / ssim,
+        EarlyStopping(val_loss, patience 3, restore_best_weights), ReduceLROnPlateau(val_loss, factor 0.5, patience 2, min_lr 1e-7).
+        Returns (history, epoch-time record, epoch-memory record) like the reference's (history, callbacks[2], callbacks[3])."""
+        if self.model is None:
+            raise ValueError("Model has not been set up.")
+        if self.compute_dtype not in ("f32", "float32"):
+            raise ValueError("training runs in fp32 (the reference's precision); build the model with compute_dtype='f32'")
+        from sr355 import train as T
+        print("Training on GPU:", torch.cuda.get_device_name(self.ctx.torch_device))
+        opt = T.Adam(self.weights, learning_rate=self.learning_rate, epsilon=1e-7)
+        weights, history, tcb, mcb = T.fit(self.ctx, self.weights, T.srcnn_loss_and_grads, self._predict_with, opt, X_train, Y_train, X_val, Y_val,
+                                           batch_size=batch_size, epochs=epochs, es_patience=3, lr_patience=2, shuffle=shuffle, verbose=verbose)
+        self.set_weights(weights)
+        self._trained = True
+        return history, tcb, mcb
+
+    def _predict_with(self, ctx, weights, x):
+        if weights is not getattr(self, "_loaded_for_predict", None):
+            self.model.set_weights(weights)
+            self._loaded_for_predict = weights
+        return self.model.forward(x)
 
     def evaluate(self, X_test, Y_test):
         if not self._trained:
@@ -54,10 +74,8 @@ class SRCNNModel(DeviceModelMixin):
             raise RuntimeError("Model has not been trained.")
         if lr_img is None or not isinstance(lr_img, (np.ndarray, torch.Tensor)):
             raise ValueError("lr_img must be a numpy array (RGB).")
-        if interpolation != INTER_CUBIC:
-            raise NotImplementedError("only cv2.INTER_CUBIC is on the accelerated path")
         lr, is_np = P.as_device_image(self.ctx, lr_img)
-        up = self.ctx.bicubic(lr[None], int(hr_h), int(hr_w))[0]
+        up = self.ctx.resize(lr[None], int(hr_h), int(hr_w), interpolation)[0]       # any of OpenCV's four resize codes
         sr, metrics = P.patchwise_sr(self.model, up, patch_size, stride, 1, chunk=256)
         return (sr.cpu().numpy() if is_np else sr), metrics
 

@@ -953,6 +953,27 @@ int sr_mse(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, vo
     return mse_launch(ctx, static_cast<const float*>(a), static_cast<const float*>(b), n, out1, static_cast<hipStream_t>(stream));
 }
 
+int sr_conv2d_wgrad(sr_ctx* ctx, const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, int K, float* dw_hwio, float* db, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!x || !dy || !dw_hwio) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return wgrad_launch(ctx, static_cast<const float*>(x), static_cast<const float*>(dy), B, H, W, Cin, Cout, K, dw_hwio, db, static_cast<hipStream_t>(stream));
+}
+
+int sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, float beta, void* out, int64_t n, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !out) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return eltwise_launch(ctx, op, static_cast<const float*>(a), static_cast<const float*>(b), alpha, beta, static_cast<float*>(out), n, static_cast<hipStream_t>(stream));
+}
+
+int sr_space_to_depth(sr_ctx* ctx, const void* x, int B, int H, int W, int C, int r, void* y, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!x || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return space_to_depth_launch(ctx, static_cast<const float*>(x), B, H, W, C, r, static_cast<float*>(y), static_cast<hipStream_t>(stream));
+}
+
 int sr_l1(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream) {
     DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;

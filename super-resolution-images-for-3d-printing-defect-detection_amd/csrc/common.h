@@ -168,6 +168,9 @@ int subsample2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W
 int vgg_preproc_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, void* y, int out_dtype, int Cp, hipStream_t st);
 int l1_launch(sr_ctx* ctx, const float* a, const float* b, int64_t n, float* out, hipStream_t st);
 int spectral_l1_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float* out, hipStream_t st);
+int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS, float* dw, float* db, hipStream_t st);
+int eltwise_launch(sr_ctx* ctx, int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n, hipStream_t st);
+int space_to_depth_launch(sr_ctx* ctx, const float* x, int B, int H, int W, int C, int r, float* y, hipStream_t st);
 int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, int interp, void* y, hipStream_t st);
 int psnr_launch(sr_ctx* ctx, const float* a, const float* b, int B, int64_t n_per_image, float max_val, float* out,
                 hipStream_t st);

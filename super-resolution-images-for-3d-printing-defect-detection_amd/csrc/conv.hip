@@ -302,6 +302,7 @@ int dispatch(sr_ctx* ctx, const ConvWeights& w, const ConvParams& p, int nct, hi
     if (w.thin) {
         switch (w.KS) {
             case 3: return dispatch_thin_nt<T, 3>(ctx, p, w.NT, nct, st);
+            case 5: return dispatch_thin_nt<T, 5>(ctx, p, w.NT, nct, st);      // input gradient of SRCNN's 5x5 32 -> 3 conv (3 -> 32 on dy)
             case 9: return dispatch_thin_nt<T, 9>(ctx, p, w.NT, nct, st);
         }
     } else {

@@ -15,6 +15,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2
 MODEL_SRCNN, MODEL_EDSR, MODEL_ESRGAN_G, MODEL_VGG16, MODEL_ESRGAN_D, MODEL_VGG19_FEATURES = 0, 1, 2, 3, 4, 5
 ACT_LINEAR, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 WEIGHT_KERNEL, WEIGHT_BIAS = 0, 1
+ELT_AXPBY, ELT_RELU_BWD, ELT_LRELU_BWD, ELT_CLIP01_BWD, ELT_MUL, ELT_TANH_BWD, ELT_CLIP01 = 0, 1, 2, 3, 4, 5, 6
 
 
 class ModelCfg(C.Structure):
@@ -60,6 +61,9 @@ SIGNATURES = {
     "sr_psnr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "sr_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sr_eltwise": (_i, [_vp, _i, _vp, _vp, _f, _f, _vp, _i64, _vp]),
+    "sr_space_to_depth": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_l1": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sr_spectral_l1": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sr_extract_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i64, C.POINTER(_i), _vp]),

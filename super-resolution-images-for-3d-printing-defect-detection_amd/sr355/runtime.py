@@ -211,6 +211,42 @@ class Context:
         self.check(self.lib.sr_mse(self.h, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), self.stream()))
         return out
 
+    # ------------------------------------------------------------------ backward-pass pieces (sr355/train.py)
+    def conv2d_wgrad(self, x, dy, k):
+        """Kernel and bias gradient of Conv2D(k x k, SAME, stride 1): x [B,H,W,Cin], dy [B,H,W,Cout] fp32 -> (dw HWIO, db) device tensors."""
+        _check_tensor(self, x, "wgrad x")
+        _check_tensor(self, dy, "wgrad dy")
+        B, H, W, cin = x.shape
+        if tuple(dy.shape[:3]) != (B, H, W):
+            raise ValueError("wgrad: x and dy must share [B,H,W]")
+        cout = dy.shape[3]
+        dw = self.empty((k, k, cin, cout), torch.float32)
+        db = self.empty((cout,), torch.float32)
+        self.check(self.lib.sr_conv2d_wgrad(self.h, x.data_ptr(), dy.data_ptr(), B, H, W, cin, cout, int(k), dw.data_ptr(), db.data_ptr(), self.stream()))
+        return dw, db
+
+    def eltwise(self, op, a, b=None, alpha=1.0, beta=0.0):
+        """Element-wise halves of the chain rule (L.ELT_*): fp32 tensors of one shape -> new tensor."""
+        _check_tensor(self, a, "eltwise a")
+        if b is not None:
+            _check_tensor(self, b, "eltwise b")
+            if b.shape != a.shape:
+                raise ValueError("eltwise operands must have the same shape")
+        out = torch.empty_like(a)
+        self.check(self.lib.sr_eltwise(self.h, int(op), a.data_ptr(), None if b is None else b.data_ptr(), float(alpha), float(beta), out.data_ptr(),
+                                       a.numel(), self.stream()))
+        return out
+
+    def space_to_depth(self, x, r):
+        """Inverse of tf.nn.depth_to_space (DCR): [B,H*r,W*r,C] -> [B,H,W,r*r*C]."""
+        _check_tensor(self, x, "space_to_depth input")
+        B, Hr, Wr, Cx = x.shape
+        if Hr % r or Wr % r:
+            raise ValueError("space_to_depth: spatial size not divisible by the block")
+        y = self.empty((B, Hr // r, Wr // r, r * r * Cx), torch.float32)
+        self.check(self.lib.sr_space_to_depth(self.h, x.data_ptr(), B, Hr // r, Wr // r, Cx, int(r), y.data_ptr(), self.stream()))
+        return y
+
     def l1(self, a, b):
         """mean |a - b| (ESRGAN _pixel_loss) -> [1] tensor."""
         _check_tensor(self, a, "l1 input a")

@@ -1,0 +1,206 @@
+"""Keras `model.fit` for the SRCNN and EDSR graphs on MI355X (reference: SRCNN_model.py:55-98, EDSR_model.py:127-176).
+
+What the reference delegates to Keras is restated here as host orchestration over the C ABI: forward convs (the MFMA kernels, fp32 as
+the reference trains), loss = mean_squared_error, the backward pass layer by layer -- input gradients are the SAME forward kernels on
+180-degree-rotated, channel-swapped weights, weight / bias gradients the fp32-MFMA wgrad kernel, activations / clip / depth_to_space
+their element-wise or permutation inverses (csrc/train_ops.hip) -- and Adam exactly as Keras applies it (optimizer_v2 dense update:
+lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); var -= lr_t m / (sqrt(v) + eps); EDSR: per-variable clip-by-norm 1.0, eps 1e-8), plus the two
+callbacks that change the result (EarlyStopping with restore_best_weights, ReduceLROnPlateau) and the two that only record
+(epoch time, device memory).  Optimiser state and master weights live on the host (28 931 / 1.37 M parameters); every step re-packs the
+updated kernels for the device through the single-op entry points.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _rot(w):
+    """Kernel of the input-gradient conv: rotate by 180 degrees, swap the channel axes (HWIO -> HW O I)."""
+    return np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))
+
+
+class Adam:
+    """keras.optimizers.Adam (TF 2.10 optimizer_v2), dense update, fp32 state."""
+
+    def __init__(self, weights, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=None):
+        self.lr, self.b1, self.b2, self.eps, self.clipnorm = float(learning_rate), beta_1, beta_2, epsilon, clipnorm
+        self.t = 0
+        self.m = {n: [np.zeros_like(k), np.zeros_like(b)] for n, (k, b) in weights.items()}
+        self.v = {n: [np.zeros_like(k), np.zeros_like(b)] for n, (k, b) in weights.items()}
+
+    def apply(self, weights, grads):
+        self.t += 1
+        lr_t = np.float32(self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t))
+        out = {}
+        for n, (k, b) in weights.items():
+            new = []
+            for slot, (var, g) in enumerate(((k, grads[n][0]), (b, grads[n][1]))):
+                g = np.asarray(g, np.float32)
+                if self.clipnorm is not None:                      # tf.clip_by_norm per variable
+                    nrm = float(np.sqrt(np.sum(g.astype(np.float64) ** 2)))
+                    if nrm > self.clipnorm:
+                        g = g * np.float32(self.clipnorm / nrm)
+                m = self.m[n][slot] = np.float32(self.b1) * self.m[n][slot] + np.float32(1.0 - self.b1) * g
+                v = self.v[n][slot] = np.float32(self.b2) * self.v[n][slot] + np.float32(1.0 - self.b2) * g * g
+                new.append((var - lr_t * m / (np.sqrt(v) + np.float32(self.eps))).astype(np.float32))
+            out[n] = (new[0], new[1])
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- graphs
+def srcnn_loss_and_grads(ctx, w, x, t):
+    """SRCNN_model.py:48-53 + mean_squared_error.  x, t device fp32 [B,H,W,3].  -> (prediction, loss tensor [1], {layer: (dw, db)})."""
+    a1 = ctx.conv2d(x, *w["conv2d"], act="relu")
+    a2 = ctx.conv2d(a1, *w["conv2d_1"], act="relu")
+    y = ctx.conv2d(a2, *w["conv2d_2"])
+    loss = ctx.mse(t, y)
+    g = {}
+    dy = ctx.eltwise(L.ELT_AXPBY, y, t, 2.0 / y.numel(), -2.0 / y.numel())
+    g["conv2d_2"] = ctx.conv2d_wgrad(a2, dy, 5)
+    d2 = ctx.eltwise(L.ELT_RELU_BWD, ctx.conv2d(dy, _rot(w["conv2d_2"][0])), a2)
+    g["conv2d_1"] = ctx.conv2d_wgrad(a1, d2, 1)
+    d1 = ctx.eltwise(L.ELT_RELU_BWD, ctx.conv2d(d2, _rot(w["conv2d_1"][0])), a1)
+    g["conv2d"] = ctx.conv2d_wgrad(x, d1, 9)
+    return y, loss, g
+
+
+def edsr_loss_and_grads(ctx, w, x, t, scale=2, num_res_blocks=16, res_scaling=0.1):
+    """EDSR_model.py:55-125 + mean_squared_error (the compile step ignores its loss argument, :137)."""
+    names = ["conv2d"] + [f"conv2d_{i}" for i in range(1, 2 * num_res_blocks + 5)]
+    it = iter(names)
+    n_head = next(it)
+    h0 = ctx.conv2d(x, *w[n_head])
+    cur, blocks = h0, []
+    for _ in range(num_res_blocks):
+        na, nb = next(it), next(it)
+        tt = ctx.conv2d(cur, *w[na], act="relu")
+        nxt = ctx.conv2d(tt, *w[nb], alpha=res_scaling, skip1=cur, beta1=1.0)
+        blocks.append((na, nb, cur, tt))
+        cur = nxt
+    n_body = next(it)
+    body = ctx.conv2d(cur, *w[n_body], skip1=h0, beta1=1.0)
+    ups, up = [], body
+    for r in ([scale] if scale in (2, 3) else [2, 2]):
+        nu = next(it)
+        v = ctx.conv2d(up, *w[nu], d2s=r)
+        ups.append((nu, up, r))
+        up = v
+    n_out = next(it)
+    pre = ctx.conv2d(up, *w[n_out])
+    y = ctx.eltwise(L.ELT_CLIP01, pre)
+    loss = ctx.mse(t, y)
+    g = {}
+    dy = ctx.eltwise(L.ELT_AXPBY, y, t, 2.0 / y.numel(), -2.0 / y.numel())
+    dpre = ctx.eltwise(L.ELT_CLIP01_BWD, dy, pre)
+    g[n_out] = ctx.conv2d_wgrad(up, dpre, 3)
+    d = ctx.conv2d(dpre, _rot(w[n_out][0]))
+    for nu, uin, r in reversed(ups):
+        dv = ctx.space_to_depth(d, r)
+        g[nu] = ctx.conv2d_wgrad(uin, dv, 3)
+        d = ctx.conv2d(dv, _rot(w[nu][0]))
+    d_h0 = d                                                  # global skip: body = conv(cur) + h0
+    g[n_body] = ctx.conv2d_wgrad(cur, d, 3)
+    d = ctx.conv2d(d, _rot(w[n_body][0]))
+    for na, nb, cin, tt in reversed(blocks):
+        du = ctx.eltwise(L.ELT_AXPBY, d, None, res_scaling, 0.0)
+        g[nb] = ctx.conv2d_wgrad(tt, du, 3)
+        dt = ctx.eltwise(L.ELT_RELU_BWD, ctx.conv2d(du, _rot(w[nb][0])), tt)
+        g[na] = ctx.conv2d_wgrad(cin, dt, 3)
+        d = ctx.eltwise(L.ELT_AXPBY, d, ctx.conv2d(dt, _rot(w[na][0])), 1.0, 1.0)
+    d = ctx.eltwise(L.ELT_AXPBY, d, d_h0, 1.0, 1.0)
+    g[n_head] = ctx.conv2d_wgrad(x, d, 3)
+    return y, loss, g
+
+
+# ---------------------------------------------------------------------------------------------------------------- fit
+class History:
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+class EpochTimeRecord:
+    """EpochTimeCallback's record (callbacks.py:21-42)."""
+    def __init__(self):
+        self.epoch_times_sec = []
+
+    def mean_time_value(self):
+        return float(np.mean(self.epoch_times_sec))
+
+
+class EpochMemoryRecord:
+    """EpochMemoryCallback's record (callbacks.py:44-): device memory held by libsr355, MB."""
+    def __init__(self):
+        self.gpu_mean_current_mb = []
+        self.gpu_peak_mb = []
+
+
+def fit(ctx, weights, loss_and_grads, predict, optimizer, X_train, Y_train, X_val, Y_val, batch_size=16, epochs=50, es_patience=3,
+        lr_patience=2, lr_factor=0.5, min_lr=1e-7, shuffle=True, seed=42, verbose=True):
+    """model.fit(X, Y, batch_size, epochs, validation_data, callbacks=[EarlyStopping(val_loss, patience, restore_best_weights=True),
+    ReduceLROnPlateau(val_loss, factor, patience, min_lr), EpochTimeCallback, EpochMemoryCallback]).
+    weights: {layer: (kernel, bias)} host fp32 (updated copy returned).  -> (weights, History, EpochTimeRecord, EpochMemoryRecord)."""
+    X_train, Y_train = np.asarray(X_train, np.float32), np.asarray(Y_train, np.float32)
+    X_val, Y_val = np.asarray(X_val, np.float32), np.asarray(Y_val, np.float32)
+    hist, tcb, mcb = History(), EpochTimeRecord(), EpochMemoryRecord()
+    for k in ("loss", "psnr", "ssim", "val_loss", "val_psnr", "val_ssim", "lr"):
+        hist.history[k] = []
+    rng = np.random.default_rng(seed)
+    best, best_w, es_wait, lr_wait, lr_best = np.inf, None, 0, 0, np.inf
+    n = len(X_train)
+    for ep in range(epochs):
+        mem0 = ctx.mem_info()
+        t0 = time.perf_counter()
+        order = rng.permutation(n) if shuffle else np.arange(n)
+        tot = np.zeros(3, np.float64)
+        for i in range(0, n, batch_size):
+            idx = order[i:i + batch_size]
+            x, t = ctx.to_device(X_train[idx]), ctx.to_device(Y_train[idx])
+            y, loss, grads = loss_and_grads(ctx, weights, x, t)
+            k = len(idx)
+            tot += [float(loss.item()) * k, float(ctx.psnr(t, y).sum().item()), float(ctx.ssim(t, y).sum().item())]
+            host_g = {name: (dw.cpu().numpy(), db.cpu().numpy()) for name, (dw, db) in grads.items()}
+            weights = optimizer.apply(weights, host_g)
+        vt = np.zeros(3, np.float64)
+        for i in range(0, len(X_val), batch_size):
+            x, t = ctx.to_device(X_val[i:i + batch_size]), ctx.to_device(Y_val[i:i + batch_size])
+            y = predict(ctx, weights, x)
+            vt += [float(ctx.mse(t, y).item()) * len(x), float(ctx.psnr(t, y).sum().item()), float(ctx.ssim(t, y).sum().item())]
+        torch.cuda.synchronize(ctx.torch_device)
+        tr, va = tot / max(n, 1), vt / max(len(X_val), 1)
+        for key, val in zip(("loss", "psnr", "ssim", "val_loss", "val_psnr", "val_ssim"), list(tr) + list(va)):
+            hist.history[key].append(float(val))
+        hist.history["lr"].append(optimizer.lr)
+        hist.epoch.append(ep)
+        tcb.epoch_times_sec.append(time.perf_counter() - t0)
+        mem1 = ctx.mem_info()
+        mcb.gpu_mean_current_mb.append((mem0["current"] + mem1["current"]) / 2.0 / (1024.0 * 1024.0))
+        mcb.gpu_peak_mb.append(max(mem0["peak"], mem1["peak"]) / (1024.0 * 1024.0))
+        if verbose:
+            print(f"Epoch {ep + 1}/{epochs} - loss: {tr[0]:.4f} - psnr: {tr[1]:.4f} - ssim: {tr[2]:.4f} - val_loss: {va[0]:.4f} - "
+                  f"val_psnr: {va[1]:.4f} - val_ssim: {va[2]:.4f} - lr: {optimizer.lr:.2e}")
+        # ReduceLROnPlateau(monitor="val_loss", mode min, min_delta 1e-4, cooldown 0)
+        if va[0] < lr_best - 1e-4:
+            lr_best, lr_wait = va[0], 0
+        else:
+            lr_wait += 1
+            if lr_wait >= lr_patience and optimizer.lr > min_lr:
+                optimizer.lr = max(optimizer.lr * lr_factor, min_lr)
+                lr_wait = 0
+                if verbose:
+                    print(f"Epoch {ep + 1}: ReduceLROnPlateau reducing learning rate to {optimizer.lr}.")
+        # EarlyStopping(monitor="val_loss", min_delta 0, restore_best_weights=True)
+        if va[0] < best:
+            best, es_wait = va[0], 0
+            best_w = {k2: (a.copy(), b.copy()) for k2, (a, b) in weights.items()}
+        else:
+            es_wait += 1
+            if es_wait >= es_patience:
+                weights = best_w
+                if verbose:
+                    print(f"Epoch {ep + 1}: early stopping; restoring model weights from the end of the best epoch.")
+                break
+    return weights, hist, tcb, mcb
