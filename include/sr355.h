@@ -44,8 +44,9 @@ enum { SR_MODEL_SRCNN = 0, SR_MODEL_EDSR = 1, SR_MODEL_ESRGAN_G = 2, SR_MODEL_VG
 enum { SR_ACT_LINEAR = 0, SR_ACT_RELU = 1, SR_ACT_LRELU = 2, SR_ACT_TANH = 3 };
 enum { SR_WEIGHT_KERNEL = 0, SR_WEIGHT_BIAS = 1 };
 /* sr_eltwise ops: out = alpha*a + beta*b | dy where y > 0 | dy (0.2 dy where y <= 0) | dy where 0 <= x <= 1 | alpha*a*b | dy*(1 - y^2) |
- * clip(a, 0, 1) */
-enum { SR_ELT_AXPBY = 0, SR_ELT_RELU_BWD = 1, SR_ELT_LRELU_BWD = 2, SR_ELT_CLIP01_BWD = 3, SR_ELT_MUL = 4, SR_ELT_TANH_BWD = 5, SR_ELT_CLIP01 = 6 };
+ * clip(a, 0, 1) | alpha * sign(a - b) */
+enum { SR_ELT_AXPBY = 0, SR_ELT_RELU_BWD = 1, SR_ELT_LRELU_BWD = 2, SR_ELT_CLIP01_BWD = 3, SR_ELT_MUL = 4, SR_ELT_TANH_BWD = 5, SR_ELT_CLIP01 = 6,
+       SR_ELT_SIGN_DIFF = 7 };
 
 /* Architecture hyper-parameters = the keyword arguments of the reference's setup_model():
  * SRCNN_model.py:23, EDSR_model.py:29, ESRGAN_model.py:108, VGG16_model.py:21. */
@@ -183,6 +184,23 @@ int  sr_conv2d_wgrad(sr_ctx* ctx, const void* x, const void* dy, int B, int H, i
                      float* dw_hwio, float* db, void* stream);
 int  sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, float beta, void* out, int64_t n, void* stream);
 int  sr_space_to_depth(sr_ctx* ctx, const void* x, int B, int H, int W, int C, int r, void* y, void* stream);
+/* More halves of ESRGAN._train_step's backward pass (ESRGAN_model.py:475-533), fp32 device tensors:
+ * sr_matmul: C[b] = alpha * op(A[b]) op(B[b]) (row-major, op = transpose when the flag is set) -- the MATERIALISED SelfAttention of the
+ *   24x24 / 48x48 training patches (:57-65) and its six backward products; sr_softmax_rows / sr_softmax_bwd: softmax over the last axis in
+ *   place, and ds = p * (dp - <dp, p>).
+ * sr_maxpool2_bwd: MaxPooling2D(2,2) gradient (VGG19 extractor); sr_zero_insert2: adjoint of the stride-2 pick of the discriminator's
+ *   strided convs (dy [B,ceil(H/2),ceil(W/2),C] -> [B,H,W,C]); sr_spectral_l1_bwd: gradient of scale * sr_spectral_l1 w.r.t. a. */
+/* sr_spatial_op: the non-conv layers of the discriminator / VGG19 graphs as single ops, x f32 [B,H,W,C] -> y:
+ *   SR_SP_MAXPOOL2 [B,H/2,W/2,C] (MaxPooling2D(2,2) VALID), SR_SP_GAP [B,C] (GlobalAveragePooling2D), SR_SP_PICK2 [B,ceil(H/2),ceil(W/2),C]
+ *   (the sampling half of a stride-2 SAME conv, see SR_MODEL_ESRGAN_D), SR_SP_VGG_PREPROCESS [B,H,W,3] (ESRGAN_model.py:401-408). */
+enum { SR_SP_MAXPOOL2 = 0, SR_SP_GAP = 1, SR_SP_PICK2 = 2, SR_SP_VGG_PREPROCESS = 3 };
+int  sr_spatial_op(sr_ctx* ctx, int op, const void* x, int B, int H, int W, int C, void* y, void* stream);
+int  sr_matmul(sr_ctx* ctx, const void* A, const void* B, void* C, int batch, int M, int N, int K, int transA, int transB, float alpha, void* stream);
+int  sr_softmax_rows(sr_ctx* ctx, void* s, int64_t rows, int cols, void* stream);
+int  sr_softmax_bwd(sr_ctx* ctx, const void* p, const void* dp, void* ds, int64_t rows, int cols, void* stream);
+int  sr_maxpool2_bwd(sr_ctx* ctx, const void* x, const void* dy, int B, int H, int W, int C, void* dx, void* stream);
+int  sr_zero_insert2(sr_ctx* ctx, const void* dy, int B, int H, int W, int C, void* out, void* stream);
+int  sr_spectral_l1_bwd(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float scale, void* da, void* stream);
 /* add_padding + sliding-window extraction (SRCNN_model.py:127-162, EDSR_model.py:201-223,
  * ESRGAN_model.py:883-901, VGG16_model.py:216-239): img f32 [H,W,C] (unpadded), reflect padding
  * bottom/right computed from (patch,stride); out [P,patch,patch,C] of out_dtype, each value

@@ -74,6 +74,9 @@ class AdamRef:
         lr_t = self.lr * np.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
         out = {}
         for n, (k, b) in w.items():
+            if n not in g:
+                out[n] = (k, b)
+                continue
             new = []
             for s, (var, gr) in enumerate(((k, g[n][0]), (b, g[n][1]))):
                 gr = np.asarray(gr, np.float64)
@@ -98,3 +101,168 @@ def train_steps(forward, w, batches, lr, epsilon=1e-7, clipnorm=None, **kw):
         losses.append(loss)
         w = opt.apply(w, g)
     return w, losses
+
+
+# =====================================================================================================================
+# ESRGAN._train_step (ESRGAN_model.py:475-533) in torch autograd, fp64
+# =====================================================================================================================
+def _act(x, act):
+    if act == "relu":
+        return F.relu(x)
+    if act == "lrelu":
+        return F.leaky_relu(x, 0.2)
+    if act == "tanh":
+        return torch.tanh(x)
+    return x
+
+
+def _conv_s(x, k, b, act=None, stride=1):
+    """Keras Conv2D SAME with TF's asymmetric padding for stride 2; x NCHW."""
+    kt = k.permute(3, 2, 0, 1)
+    kh = k.shape[0]
+    pads = []
+    for n in (x.shape[3], x.shape[2]):                    # F.pad order: W first
+        out = -(-n // stride)
+        tot = max((out - 1) * stride + kh - n, 0)
+        pads += [tot // 2, tot - tot // 2]
+    return _act(F.conv2d(F.pad(x, pads), kt, b, stride=stride), act)
+
+
+def _sa_t(p, x, name):
+    """SelfAttention.call (ESRGAN_model.py:48-70) on NCHW."""
+    B, C, H, W = x.shape
+    f = _conv_s(x, *p[name + "_f"]).reshape(B, -1, H * W)          # [B,8,N]
+    g = _conv_s(x, *p[name + "_g"]).reshape(B, -1, H * W)
+    h = _conv_s(x, *p[name + "_h"]).reshape(B, -1, H * W)
+    s = torch.matmul(g.transpose(1, 2), f)                        # [B,N,N] = g f^T
+    beta = torch.softmax(s, dim=-1)
+    o = torch.matmul(beta, h.transpose(1, 2)).transpose(1, 2).reshape(B, -1, H, W)
+    return x + _conv_s(o, *p[name + "_v"])
+
+
+def generator_forward_t(p, x, scale, num_rrdb, attention=True):
+    x = _conv_s(x, *p["initial_conv"])
+    trunk = x
+    for b in range(num_rrdb):
+        r_in = x
+        for d in (1, 2, 3):
+            n = f"rrdb_{b}_dense{d}"
+            feats = [x]
+            for k in range(1, 5):
+                feats.append(_conv_s(torch.cat(feats, dim=1), *p[f"{n}_conv{k}"], act="relu"))
+            x = x + 0.2 * _conv_s(torch.cat(feats, dim=1), *p[f"{n}_conv5"])
+        x = r_in + 0.2 * x
+    x = trunk + _conv_s(x, *p["trunk_conv"])
+    if attention:
+        x = _sa_t(p, x, "self_attention_trunk")
+    i, s = 0, scale
+    while s > 1:
+        x = F.leaky_relu(_d2s(_conv_s(x, *p[f"upsample_{i}_conv"]), 2), 0.2)
+        if i == 0 and attention:
+            x = _sa_t(p, x, "self_attention_upsample_0")
+        s >>= 1
+        i += 1
+    x = _conv_s(x, *p["final_conv1"], act="relu")
+    return _conv_s(x, *p["final_conv2"], act="tanh")
+
+
+DISC_NAMES = [f"disc_conv{i}" for i in range(1, 7)] + ["disc_dense1", "disc_output"]
+
+
+def _sn_inplace(w, u):
+    """tfa SpectralNormalization on every wrapper (training=True): kernel.assign(kernel / sigma), u.assign(u)."""
+    from . import ops
+    w, u = dict(w), dict(u)
+    for n in DISC_NAMES:
+        k, nu = ops.spectral_normalize(np.asarray(w[n][0], np.float64), u[n])
+        w[n], u[n] = (k, w[n][1]), nu
+    return w, u
+
+
+def discriminator_forward_t(p, x):
+    for i, st in enumerate([1, 2, 1, 2, 1, 2]):
+        x = _conv_s(x, *p[f"disc_conv{i + 1}"], act="lrelu", stride=st)
+    g = x.mean(dim=(2, 3))
+    g = F.leaky_relu(g @ p["disc_dense1"][0] + p["disc_dense1"][1], 0.2)
+    return torch.sigmoid(g @ p["disc_output"][0] + p["disc_output"][1])
+
+
+def vgg19_features_t(p, x):
+    """x NCHW in [-1,1] -> block5_conv4 features (caffe preprocessing inside)."""
+    x = (x + 1.0) * 127.5
+    x = x.flip(1) - torch.tensor([103.939, 116.779, 123.68], dtype=x.dtype).reshape(1, 3, 1, 1)
+    for blk, n in ((1, 2), (2, 2), (3, 4), (4, 4), (5, 4)):
+        for k in range(1, n + 1):
+            x = _conv_s(x, *p[f"block{blk}_conv{k}"], act="relu")
+            if (blk, k) == (5, 4):
+                return x
+        x = F.max_pool2d(x, 2)
+    return x
+
+
+def _bce(t, p, eps=1e-7):
+    pc = torch.clamp(p, eps, 1.0 - eps)
+    return torch.mean(-(t * torch.log(pc + eps) + (1.0 - t) * torch.log(1.0 - pc + eps)))
+
+
+def _grads(p):
+    return {n: (k.grad.numpy().copy(), b.grad.numpy().copy()) for n, (k, b) in p.items() if k.grad is not None}
+
+
+def esrgan_train_step_ref(gw, dw, u, vw, lr_img, hr_img, scale, num_rrdb, attention=True, g_lr=1e-4, d_lr=1e-5, g_opt=None, d_opt=None,
+                          dy_override=None):
+    """One _train_step.  gw / dw / vw: {layer: (kernel, bias)}; u: {layer: [1,Cout]}; images NHWC in [-1,1].
+    -> dict(losses, g_grads, d_grads, gw, dw, u, g_opt, d_opt, dy, y) with the updated state (fp64).
+    dy_override (NHWC) replaces d g_loss / d G(lr) in the generator's backward pass: the loss gradient has kinks (ReLU / max-pool /
+    |.| in the loss networks) where two correct implementations that differ in the last bit of y may legitimately take different
+    branches, so a test checks dy itself away from those kinks and the generator's backward on one common dy."""
+    f64 = lambda w: {n: (np.asarray(k, np.float64), np.asarray(b, np.float64)) for n, (k, b) in w.items()}
+    gw, dw, vw = f64(gw), f64(dw), f64(vw)
+    g_opt = g_opt or AdamRef(gw, g_lr)
+    d_opt = d_opt or AdamRef(dw, d_lr)
+    x = torch.tensor(np.asarray(lr_img, np.float64)).permute(0, 3, 1, 2)
+    hr = torch.tensor(np.asarray(hr_img, np.float64)).permute(0, 3, 1, 2)
+    # ---- discriminator update: D(real) with K1 = SN(K0), D(fake) with K2 = SN(K1); gradients add; Adam acts on K2
+    with torch.no_grad():
+        fake = generator_forward_t(_params(gw), x, scale, num_rrdb, attention)
+    dw, u = _sn_inplace(dw, u)
+    p1 = _params(dw)
+    d_real = discriminator_forward_t(p1, hr)
+    l_real = _bce(torch.ones_like(d_real), d_real)
+    l_real.backward()
+    dw, u = _sn_inplace(dw, u)
+    p2 = _params(dw)
+    d_fake = discriminator_forward_t(p2, fake)
+    l_fake = _bce(torch.zeros_like(d_fake), d_fake)
+    l_fake.backward()
+    g1, g2 = _grads(p1), _grads(p2)
+    d_grads = {n: (g1[n][0] + g2[n][0], g1[n][1] + g2[n][1]) for n in g1}
+    dw = d_opt.apply(dw, d_grads)
+    # ---- generator update (third renormalisation of D)
+    pg = _params(gw)
+    y = generator_forward_t(pg, x, scale, num_rrdb, attention)
+    y.retain_grad()
+    dw, u = _sn_inplace(dw, u)
+    pd = {n: (torch.tensor(k), torch.tensor(b)) for n, (k, b) in dw.items()}
+    pv = {n: (torch.tensor(k), torch.tensor(b)) for n, (k, b) in vw.items()}
+    d_f = discriminator_forward_t(pd, y)
+    adv = _bce(torch.ones_like(d_f), d_f)
+    perc = torch.mean((vgg19_features_t(pv, hr) - vgg19_features_t(pv, y)) ** 2)
+    pix = torch.mean(torch.abs(hr - y))
+    yn, hn = y.permute(0, 2, 3, 1), hr.permute(0, 2, 3, 1)                       # NHWC: fft2 over the innermost (W, C) axes
+    spec = torch.mean(torch.abs(torch.abs(torch.fft.fft2(hn.to(torch.complex128))) - torch.abs(torch.fft.fft2(yn.to(torch.complex128)))))
+    g_loss = adv + 1.0 * perc + 100.0 * pix + 1.0 * spec
+    g_loss.backward(retain_graph=dy_override is not None)
+    dy = y.grad.permute(0, 2, 3, 1).numpy().copy()
+    if dy_override is not None:
+        for k_, b_ in pg.values():
+            k_.grad = None
+            b_.grad = None
+        y.backward(torch.tensor(np.asarray(dy_override, np.float64)).permute(0, 3, 1, 2))
+    g_grads = _grads(pg)
+    gw = g_opt.apply(gw, g_grads)
+    val = lambda t_: float(t_.detach().item())
+    losses = {"g_loss": val(g_loss), "d_loss": val(l_real + l_fake), "adversarial": val(adv), "perceptual": val(perc), "pixel": val(pix),
+              "spectral": val(spec)}
+    return dict(losses=losses, g_grads=g_grads, d_grads=d_grads, gw=gw, dw=dw, u=u, g_opt=g_opt, d_opt=d_opt,
+                dy=dy, y=y.detach().permute(0, 2, 3, 1).numpy())

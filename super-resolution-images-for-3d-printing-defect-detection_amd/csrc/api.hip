@@ -974,6 +974,62 @@ int sr_space_to_depth(sr_ctx* ctx, const void* x, int B, int H, int W, int C, in
     return space_to_depth_launch(ctx, static_cast<const float*>(x), B, H, W, C, r, static_cast<float*>(y), static_cast<hipStream_t>(stream));
 }
 
+int sr_spatial_op(sr_ctx* ctx, int op, const void* x, int B, int H, int W, int C, void* y, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!x || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return ctx->fail(SR_ERR_INVALID, "bad tensor shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (op) {
+        case SR_SP_MAXPOOL2: return maxpool2_launch(ctx, SR_DTYPE_F32, x, B, H, W, C, C, y, C, st);
+        case SR_SP_GAP: return gap_launch(ctx, SR_DTYPE_F32, x, B, H * W, C, C, static_cast<float*>(y), st);
+        case SR_SP_PICK2: return subsample2_launch(ctx, SR_DTYPE_F32, x, B, H, W, C, C, y, C, st);
+        case SR_SP_VGG_PREPROCESS:
+            if (C != 3) return ctx->fail(SR_ERR_INVALID, "VGG preprocessing takes RGB");
+            return vgg_preproc_launch(ctx, x, SR_DTYPE_F32, (int64_t)B * H * W, y, SR_DTYPE_F32, 3, st);
+    }
+    return ctx->fail(SR_ERR_INVALID, "unknown spatial op");
+}
+
+#define SR_F(p) static_cast<const float*>(p)
+#define SR_FM(p) static_cast<float*>(p)
+int sr_matmul(sr_ctx* ctx, const void* A, const void* B, void* C, int batch, int M, int N, int K, int transA, int transB, float alpha, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!A || !B || !C) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return matmul_launch(ctx, SR_F(A), SR_F(B), SR_FM(C), batch, M, N, K, transA, transB, alpha, static_cast<hipStream_t>(stream));
+}
+int sr_softmax_rows(sr_ctx* ctx, void* s, int64_t rows, int cols, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!s) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return softmax_rows_launch(ctx, SR_FM(s), rows, cols, static_cast<hipStream_t>(stream));
+}
+int sr_softmax_bwd(sr_ctx* ctx, const void* p, const void* dp, void* ds, int64_t rows, int cols, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!p || !dp || !ds) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return softmax_bwd_launch(ctx, SR_F(p), SR_F(dp), SR_FM(ds), rows, cols, static_cast<hipStream_t>(stream));
+}
+int sr_maxpool2_bwd(sr_ctx* ctx, const void* x, const void* dy, int B, int H, int W, int C, void* dx, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!x || !dy || !dx) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return maxpool2_bwd_launch(ctx, SR_F(x), SR_F(dy), B, H, W, C, SR_FM(dx), static_cast<hipStream_t>(stream));
+}
+int sr_zero_insert2(sr_ctx* ctx, const void* dy, int B, int H, int W, int C, void* out, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!dy || !out) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return zero_insert2_launch(ctx, SR_F(dy), B, H, W, C, SR_FM(out), static_cast<hipStream_t>(stream));
+}
+int sr_spectral_l1_bwd(sr_ctx* ctx, const void* a, const void* b, int B, int H, int W, int C, float scale, void* da, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !b || !da) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return spectral_l1_bwd_launch(ctx, SR_F(a), SR_F(b), B, H, W, C, scale, SR_FM(da), static_cast<hipStream_t>(stream));
+}
+
 int sr_l1(sr_ctx* ctx, const void* a, const void* b, int64_t n, float* out1, void* stream) {
     DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;

@@ -171,6 +171,12 @@ int spectral_l1_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H
 int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS, float* dw, float* db, hipStream_t st);
 int eltwise_launch(sr_ctx* ctx, int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n, hipStream_t st);
 int space_to_depth_launch(sr_ctx* ctx, const float* x, int B, int H, int W, int C, int r, float* y, hipStream_t st);
+int matmul_launch(sr_ctx* ctx, const float* A, const float* B, float* C, int batch, int M, int N, int K, int tA, int tB, float alpha, hipStream_t st);
+int softmax_rows_launch(sr_ctx* ctx, float* s, int64_t rows, int cols, hipStream_t st);
+int softmax_bwd_launch(sr_ctx* ctx, const float* p, const float* dp, float* ds, int64_t rows, int cols, hipStream_t st);
+int maxpool2_bwd_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int C, float* dx, hipStream_t st);
+int zero_insert2_launch(sr_ctx* ctx, const float* dy, int B, int H, int W, int C, float* out, hipStream_t st);
+int spectral_l1_bwd_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float scale, float* da, hipStream_t st);
 int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, int interp, void* y, hipStream_t st);
 int psnr_launch(sr_ctx* ctx, const float* a, const float* b, int B, int64_t n_per_image, float max_val, float* out,
                 hipStream_t st);

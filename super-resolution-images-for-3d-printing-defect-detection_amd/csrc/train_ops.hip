@@ -96,6 +96,7 @@ __global__ void eltwise_kernel(int op, const float* a, const float* b, float alp
             case SR_ELT_MUL: v = alpha * av * bv; break;
             case SR_ELT_TANH_BWD: v = av * (1.f - bv * bv); break;                     // b = tanh output
             case SR_ELT_CLIP01: v = fminf(fmaxf(av, 0.f), 1.f); break;
+            case SR_ELT_SIGN_DIFF: v = alpha * (av > bv ? 1.f : (av < bv ? -1.f : 0.f)); break;   // d/da mean|a - b| up to the 1/n in alpha
             default: v = 0.f;
         }
         out[i] = v;
@@ -113,6 +114,182 @@ __global__ void space_to_depth_kernel(const float* x, int B, int H, int W, int C
         const int64_t b = t / H;
         const int sub = cc / C, c = cc - sub * C, i = sub / r, j = sub - i * r;
         y[idx] = x[(((b * H * r) + (int64_t)h * r + i) * ((int64_t)W * r) + (int64_t)w * r + j) * C + c];
+    }
+}
+
+// C[b] = alpha * op(A[b]) op(B[b]), fp32 row-major, op = identity or transpose; a plain LDS-tiled SGEMM (64 x 64 tile, 4 x 4 per thread):
+// the materialised attention of the TRAINING patches (N = 576 / 2304 tokens, ESRGAN_model.py:57-65) and its backward products.  Not a
+// hot-path kernel: inference attention is the streaming kernel of attention.hip.
+__global__ void __launch_bounds__(256) sgemm_kernel(const float* A, const float* Bm, float* C, int M, int N, int K, int tA, int tB, float alpha,
+                                                    int64_t sA, int64_t sB, int64_t sC) {
+    __shared__ float As[16][64 + 1], Bs[16][64 + 1];
+    const float* a = A + (int64_t)blockIdx.z * sA;
+    const float* b = Bm + (int64_t)blockIdx.z * sB;
+    float* c = C + (int64_t)blockIdx.z * sC;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int kk = e / 64, mm = e - kk * 64;
+            const int gm = m0 + mm, gk = k0 + kk;
+            As[kk][mm] = (gm < M && gk < K) ? (tA ? a[(int64_t)gk * M + gm] : a[(int64_t)gm * K + gk]) : 0.f;
+            const int gn = n0 + mm;
+            Bs[kk][mm] = (gn < N && gk < K) ? (tB ? b[(int64_t)gn * K + gk] : b[(int64_t)gk * N + gn]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
+            if (gm < M && gn < N) c[(int64_t)gm * N + gn] = alpha * acc[i][j];
+        }
+}
+
+// row softmax (in place) and its backward ds = p * (dp - sum_j dp_j p_j): one workgroup per row
+__global__ void softmax_rows_kernel(float* s, int cols) {
+    __shared__ float red[256];
+    float* r = s + (int64_t)blockIdx.x * cols;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) mx = fmaxf(mx, r[j]);
+    red[threadIdx.x] = mx; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    mx = red[0]; __syncthreads();
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) { const float e = expf(r[j] - mx); r[j] = e; sum += e; }
+    red[threadIdx.x] = sum; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const float inv = 1.f / red[0];
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) r[j] *= inv;
+}
+
+__global__ void softmax_bwd_rows_kernel(const float* p, const float* dp, float* ds, int cols) {
+    __shared__ float red[256];
+    const float* pr = p + (int64_t)blockIdx.x * cols;
+    const float* dr = dp + (int64_t)blockIdx.x * cols;
+    float* o = ds + (int64_t)blockIdx.x * cols;
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) sum += pr[j] * dr[j];
+    red[threadIdx.x] = sum; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    const float dot = red[0];
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) o[j] = pr[j] * (dr[j] - dot);
+}
+
+// MaxPooling2D(2,2) backward: the gradient goes to the window's maximum (first one in row-major order on ties)
+__global__ void maxpool2_bwd_kernel(const float* x, const float* dy, int B, int H, int W, int C, float* dx) {
+    const int oH = H / 2, oW = W / 2;
+    const int64_t n = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int xq = (int)(t % W); t /= W;
+        const int yq = (int)(t % H);
+        const int64_t b = t / H;
+        const int oy = yq >> 1, ox = xq >> 1;
+        float g = 0.f;
+        if (oy < oH && ox < oW) {
+            const float* base = x + ((b * H + 2 * oy) * W + 2 * ox) * C + c;
+            const float v00 = base[0], v01 = base[C], v10 = base[(int64_t)W * C], v11 = base[(int64_t)W * C + C];
+            const float m = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+            const int arg = v00 == m ? 0 : (v01 == m ? 1 : (v10 == m ? 2 : 3));
+            if (arg == (yq & 1) * 2 + (xq & 1)) g = dy[((b * oH + oy) * oW + ox) * C + c];
+        }
+        dx[i] = g;
+    }
+}
+
+// adjoint of the stride-2 pick (subsample2_kernel): dy [B, ceil(H/2), ceil(W/2), C] scattered back into a zero [B,H,W,C]
+__global__ void zero_insert2_kernel(const float* dy, int B, int H, int W, int C, float* out) {
+    const int oH = (H + 1) / 2, oW = (W + 1) / 2, offy = (H & 1) ? 0 : 1, offx = (W & 1) ? 0 : 1;
+    const int64_t n = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int xq = (int)(t % W); t /= W;
+        const int yq = (int)(t % H);
+        const int64_t b = t / H;
+        const int ry = yq - offy, rx = xq - offx;
+        float g = 0.f;
+        if (ry >= 0 && rx >= 0 && !(ry & 1) && !(rx & 1) && (ry >> 1) < oH && (rx >> 1) < oW) g = dy[((b * oH + (ry >> 1)) * oW + (rx >> 1)) * C + c];
+        out[i] = g;
+    }
+}
+
+// gradient of _spectral_loss (mean | |F(a)| - |F(b)| | over the (W, C) transform) w.r.t. a, scaled by `scale`:
+//   da[w,c] = scale / count * Re( sum_{u,v} sgn(|Fa|-|Fb|)[u,v] * Fa[u,v]/|Fa[u,v]| * exp(+2 pi i (u w / W + v c / 3)) )
+__global__ void __launch_bounds__(256) spectral_wc_bwd_kernel(const float* a, const float* b, int W, float scale, float* da) {
+    extern __shared__ float sm[];
+    float* tw = sm;                       // [W][2]  cos, sin of 2 pi k / W
+    float* ga = tw + 2 * W;               // [W][3][2] channel DFT of a, later reused
+    float* gb = ga + 6 * W;
+    float* G = gb + 6 * W;                // [W][3][2] unit-phase * sign field in the (u, v) domain
+    const int64_t row = blockIdx.x;
+    const float* ra = a + row * W * 3;
+    const float* rb = b + row * W * 3;
+    const float c3 = -0.5f, s3 = 0.86602540378443864676f;
+    for (int k = threadIdx.x; k < W; k += blockDim.x) {
+        double s, c;
+        sincospi(2.0 * (double)k / (double)W, &s, &c);
+        tw[2 * k] = (float)c; tw[2 * k + 1] = (float)s;
+        for (int im = 0; im < 2; ++im) {
+            const float* r = im ? rb : ra;
+            float* g = im ? gb : ga;
+            const float x0 = r[3 * k], x1 = r[3 * k + 1], x2 = r[3 * k + 2];
+            g[6 * k + 0] = x0 + x1 + x2;        g[6 * k + 1] = 0.f;
+            g[6 * k + 2] = x0 + c3 * (x1 + x2); g[6 * k + 3] = -s3 * (x1 - x2);
+            g[6 * k + 4] = x0 + c3 * (x1 + x2); g[6 * k + 5] = s3 * (x1 - x2);
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 3 * W; o += blockDim.x) {
+        const int u = o / 3, v = o - 3 * u;
+        float are = 0.f, aim = 0.f, bre = 0.f, bim = 0.f;
+        int k = 0;
+        for (int w = 0; w < W; ++w) {
+            const float tc = tw[2 * k], ts = -tw[2 * k + 1];                 // exp(-i theta)
+            const float gar = ga[6 * w + 2 * v], gai = ga[6 * w + 2 * v + 1], gbr = gb[6 * w + 2 * v], gbi = gb[6 * w + 2 * v + 1];
+            are += gar * tc - gai * ts; aim += gar * ts + gai * tc;
+            bre += gbr * tc - gbi * ts; bim += gbr * ts + gbi * tc;
+            k += u; if (k >= W) k -= W;
+        }
+        const float ma = sqrtf(are * are + aim * aim), mb = sqrtf(bre * bre + bim * bim);
+        const float sg = ma > mb ? 1.f : (ma < mb ? -1.f : 0.f);
+        const float inv = ma > 0.f ? sg / ma : 0.f;
+        G[6 * u + 2 * v] = are * inv; G[6 * u + 2 * v + 1] = aim * inv;
+    }
+    __syncthreads();
+    // inverse-direction sum over u per (w, v), then over v per channel
+    for (int o = threadIdx.x; o < 3 * W; o += blockDim.x) {
+        const int w = o / 3, c = o - 3 * w;
+        float acc = 0.f;
+        for (int v = 0; v < 3; ++v) {
+            float re = 0.f, im = 0.f;
+            int k = 0;
+            for (int u = 0; u < W; ++u) {
+                const float tc = tw[2 * k], ts = tw[2 * k + 1];              // exp(+i theta)
+                const float gr = G[6 * u + 2 * v], gi = G[6 * u + 2 * v + 1];
+                re += gr * tc - gi * ts; im += gr * ts + gi * tc;
+                k += w; if (k >= W) k -= W;
+            }
+            // times exp(+2 pi i v c / 3), real part
+            const int vc = (v * c) % 3;
+            const float pc = vc == 0 ? 1.f : c3, ps = vc == 0 ? 0.f : (vc == 1 ? s3 : -s3);
+            acc += re * pc - im * ps;
+        }
+        da[row * W * 3 + o] = scale * acc;
     }
 }
 
@@ -139,7 +316,7 @@ int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int
 
 int eltwise_launch(sr_ctx* ctx, int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n, hipStream_t st) {
     if (n <= 0) return SR_OK;
-    if (op < 0 || op > SR_ELT_CLIP01) return ctx->fail(SR_ERR_INVALID, "eltwise: unknown op");
+    if (op < 0 || op > SR_ELT_SIGN_DIFF) return ctx->fail(SR_ERR_INVALID, "eltwise: unknown op");
     if (op != SR_ELT_AXPBY && op != SR_ELT_CLIP01 && !b) return ctx->fail(SR_ERR_INVALID, "eltwise: this op needs two operands");
     hipLaunchKernelGGL(eltwise_kernel, dim3(grid_n(n)), dim3(256), 0, st, op, a, b, alpha, beta, out, n);
     SR_HIP(ctx, hipGetLastError());
@@ -150,6 +327,57 @@ int space_to_depth_launch(sr_ctx* ctx, const float* x, int B, int H, int W, int 
     const int64_t n = (int64_t)B * H * W * r * r * C;
     if (n <= 0 || r < 1) return ctx->fail(SR_ERR_INVALID, "space_to_depth: bad shape");
     hipLaunchKernelGGL(space_to_depth_kernel, dim3(grid_n(n)), dim3(256), 0, st, x, B, H, W, C, r, y);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int matmul_launch(sr_ctx* ctx, const float* A, const float* B, float* C, int batch, int M, int N, int K, int tA, int tB, float alpha, hipStream_t st) {
+    if (batch <= 0 || M <= 0 || N <= 0 || K <= 0) return ctx->fail(SR_ERR_INVALID, "matmul: empty operand");
+    if (batch > 65535) return ctx->fail(SR_ERR_INVALID, "matmul: batch too large");
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0, st, A, B, C, M, N, K, tA, tB, alpha, (int64_t)M * K, (int64_t)K * N,
+                       (int64_t)M * N);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int softmax_rows_launch(sr_ctx* ctx, float* s, int64_t rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0 || rows >= (1ll << 31)) return ctx->fail(SR_ERR_INVALID, "softmax: bad shape");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, cols);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int softmax_bwd_launch(sr_ctx* ctx, const float* p, const float* dp, float* ds, int64_t rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0 || rows >= (1ll << 31)) return ctx->fail(SR_ERR_INVALID, "softmax backward: bad shape");
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, p, dp, ds, cols);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int maxpool2_bwd_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int C, float* dx, hipStream_t st) {
+    const int64_t n = (int64_t)B * H * W * C;
+    if (n <= 0) return ctx->fail(SR_ERR_INVALID, "maxpool backward: empty tensor");
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_n(n)), dim3(256), 0, st, x, dy, B, H, W, C, dx);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int zero_insert2_launch(sr_ctx* ctx, const float* dy, int B, int H, int W, int C, float* out, hipStream_t st) {
+    const int64_t n = (int64_t)B * H * W * C;
+    if (n <= 0) return ctx->fail(SR_ERR_INVALID, "zero insert: empty tensor");
+    hipLaunchKernelGGL(zero_insert2_kernel, dim3(grid_n(n)), dim3(256), 0, st, dy, B, H, W, C, out);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int spectral_l1_bwd_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float scale, float* da, hipStream_t st) {
+    if (C != 3) return ctx->fail(SR_ERR_INVALID, "spectral loss: built for 3 channels");
+    if (B <= 0 || H <= 0 || W <= 0 || W > 2048) return ctx->fail(SR_ERR_INVALID, "spectral loss backward: bad shape");
+    const int64_t rows = (int64_t)B * H;
+    const size_t lds = sizeof(float) * (size_t)(2 * W + 18 * W);
+    auto kern = spectral_wc_bwd_kernel;
+    if (lds > 48 * 1024) { if (int r2 = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return r2; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(256), lds, st, a, b, W, scale / (float)((double)rows * W * 3), da);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }

@@ -15,7 +15,8 @@ DTYPE_F32, DTYPE_BF16, DTYPE_U8 = 0, 1, 2
 MODEL_SRCNN, MODEL_EDSR, MODEL_ESRGAN_G, MODEL_VGG16, MODEL_ESRGAN_D, MODEL_VGG19_FEATURES = 0, 1, 2, 3, 4, 5
 ACT_LINEAR, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 WEIGHT_KERNEL, WEIGHT_BIAS = 0, 1
-ELT_AXPBY, ELT_RELU_BWD, ELT_LRELU_BWD, ELT_CLIP01_BWD, ELT_MUL, ELT_TANH_BWD, ELT_CLIP01 = 0, 1, 2, 3, 4, 5, 6
+SP_MAXPOOL2, SP_GAP, SP_PICK2, SP_VGG_PREPROCESS = 0, 1, 2, 3
+ELT_AXPBY, ELT_RELU_BWD, ELT_LRELU_BWD, ELT_CLIP01_BWD, ELT_MUL, ELT_TANH_BWD, ELT_CLIP01, ELT_SIGN_DIFF = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class ModelCfg(C.Structure):
@@ -64,6 +65,13 @@ SIGNATURES = {
     "sr_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sr_eltwise": (_i, [_vp, _i, _vp, _vp, _f, _f, _vp, _i64, _vp]),
     "sr_space_to_depth": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sr_spatial_op": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sr_matmul": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "sr_softmax_rows": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "sr_softmax_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "sr_maxpool2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sr_zero_insert2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sr_spectral_l1_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_l1": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sr_spectral_l1": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sr_extract_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _i64, C.POINTER(_i), _vp]),

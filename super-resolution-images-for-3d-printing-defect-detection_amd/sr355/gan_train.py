@@ -1,0 +1,350 @@
+"""ESRGAN._train_step on MI355X (reference: ESRGAN_model.py:475-533; networks :212-399, losses :401-473, optimisers :176-195).
+
+One training step = discriminator update (BCE on D(real) vs 1 and D(G(lr)) vs 0) then generator update (BCE(1, D(fake)) + 1.0 x
+perceptual + 100 x L1 + 1.0 x spectral), both Adam with a staircase learning-rate decay, D's SpectralNormalization wrappers
+renormalising their kernels in place on each of the three training=True calls.
+
+The forward and backward passes are host orchestration over the C ABI's single ops, fp32 as the reference trains:
+  * convs: the MFMA forward kernels; input gradients are the same kernels on 180-degree-rotated, channel-swapped weights; kernel / bias
+    gradients the fp32-MFMA wgrad kernel (csrc/train_ops.hip);
+  * SelfAttention of the small training patches is materialised (sr_matmul + row softmax) so that its backward is six GEMMs and a
+    softmax-backward kernel; pooling / stride-2 sampling / depth_to_space / activations / the (W,C)-FFT loss have their own adjoint kernels;
+  * a minimal reverse-mode tape (below) keeps the graph bookkeeping out of the kernels; torch is used for memory only (cat / slice /
+    flip / expand: data movement).
+Tiny vectors -- the discriminator's [B,256] dense head, BCE on [B,1], spectral-norm power iteration, Adam -- run on the host in NumPy.
+This path is functional, not fast (every layer call re-packs its weights); cfg3's throughput is not a bench line yet.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+from .train import Adam, _rot
+
+
+# ----------------------------------------------------------------------------------------------------------------- tape
+class Var:
+    __slots__ = ("v", "g", "need")
+
+    def __init__(self, v, need=True):
+        self.v, self.g, self.need = v, None, need
+
+
+class Tape:
+    """Reverse-mode bookkeeping: ops push a closure; backward() runs them last-to-first.  Parameter gradients land in `grads`
+    ({layer: [dk, db]}, summed over uses) when `wgrad` is on."""
+
+    def __init__(self, ctx, weights, wgrad=True):
+        self.ctx, self.w, self.wgrad = ctx, weights, wgrad
+        self.ops, self.grads = [], {}
+
+    def _acc(self, var, g):
+        if not var.need:
+            return
+        var.g = g if var.g is None else self.ctx.eltwise(L.ELT_AXPBY, var.g, g, 1.0, 1.0)
+
+    def _pgrad(self, name, dw, db):
+        if name in self.grads:
+            self.grads[name][0] = self.ctx.eltwise(L.ELT_AXPBY, self.grads[name][0], dw, 1.0, 1.0)
+            self.grads[name][1] = self.ctx.eltwise(L.ELT_AXPBY, self.grads[name][1], db, 1.0, 1.0)
+        else:
+            self.grads[name] = [dw, db]
+
+    # ---- ops
+    def conv(self, x, name, act="linear", d2s=1, kernel=None):
+        """Keras Conv2D SAME stride 1 (+ activation, + depth_to_space for the upsample blocks)."""
+        ctx = self.ctx
+        k, b = kernel if kernel is not None else self.w[name]
+        y = Var(ctx.conv2d(x.v, k, b, act=act, d2s=d2s))
+
+        def bwd():
+            if y.g is None:
+                return
+            dz = y.g
+            if act == "relu":
+                dz = ctx.eltwise(L.ELT_RELU_BWD, dz, y.v)
+            elif act == "lrelu":
+                dz = ctx.eltwise(L.ELT_LRELU_BWD, dz, y.v)
+            elif act == "tanh":
+                dz = ctx.eltwise(L.ELT_TANH_BWD, dz, y.v)
+            if d2s > 1:
+                dz = ctx.space_to_depth(dz, d2s)                   # activation is element-wise: its mask commutes with the shuffle
+            if self.wgrad:
+                dw, db = ctx.conv2d_wgrad(x.v, dz, k.shape[0])
+                self._pgrad(name, dw, db)
+            if x.need:
+                self._acc(x, ctx.conv2d(dz, _rot(k), None))
+        self.ops.append(bwd)
+        return y
+
+    def cat(self, xs):
+        if len(xs) == 1:
+            return xs[0]
+        y = Var(torch.cat([x.v for x in xs], dim=-1).contiguous())
+        sizes = [x.v.shape[-1] for x in xs]
+
+        def bwd():
+            if y.g is None:
+                return
+            o = 0
+            for x, c in zip(xs, sizes):
+                self._acc(x, y.g[..., o:o + c].contiguous())
+                o += c
+        self.ops.append(bwd)
+        return y
+
+    def axpby(self, a, b, alpha, beta):
+        y = Var(self.ctx.eltwise(L.ELT_AXPBY, a.v, b.v, alpha, beta))
+
+        def bwd():
+            if y.g is None:
+                return
+            self._acc(a, y.g if alpha == 1.0 else self.ctx.eltwise(L.ELT_AXPBY, y.g, None, alpha, 0.0))
+            self._acc(b, y.g if beta == 1.0 else self.ctx.eltwise(L.ELT_AXPBY, y.g, None, beta, 0.0))
+        self.ops.append(bwd)
+        return y
+
+    def attention(self, x, name):
+        """SelfAttention.call (ESRGAN_model.py:48-70), materialised: s = g f^T, beta = softmax(s), o = beta h, y = x + v(o)."""
+        ctx = self.ctx
+        B, H, W, C = x.v.shape
+        N = H * W
+        f, g, h = self.conv(x, name + "_f"), self.conv(x, name + "_g"), self.conv(x, name + "_h")
+        f3, g3, h3 = f.v.reshape(B, N, -1), g.v.reshape(B, N, -1), h.v.reshape(B, N, -1)
+        beta = ctx.softmax_rows_(ctx.matmul(g3, f3, trans_b=True))            # [B,N,N]
+        o = Var(ctx.matmul(beta, h3).reshape(B, H, W, -1))
+
+        def bwd():
+            if o.g is None:
+                return
+            do = o.g.reshape(B, N, -1)
+            dbeta = ctx.matmul(do, h3, trans_b=True)                           # [B,N,N]
+            self._acc(h, ctx.matmul(beta, do, trans_a=True).reshape(h.v.shape))
+            ds = ctx.softmax_bwd(beta, dbeta)
+            self._acc(g, ctx.matmul(ds, f3).reshape(g.v.shape))
+            self._acc(f, ctx.matmul(ds, g3, trans_a=True).reshape(f.v.shape))
+        self.ops.append(bwd)
+        ov = self.conv(o, name + "_v")
+        return self.axpby(x, ov, 1.0, 1.0)
+
+    def pick2(self, x):
+        y = Var(self.ctx.spatial_op(L.SP_PICK2, x.v))
+        H, W = x.v.shape[1:3]
+
+        def bwd():
+            if y.g is not None:
+                self._acc(x, self.ctx.zero_insert2(y.g, H, W))
+        self.ops.append(bwd)
+        return y
+
+    def maxpool(self, x):
+        y = Var(self.ctx.spatial_op(L.SP_MAXPOOL2, x.v))
+
+        def bwd():
+            if y.g is not None:
+                self._acc(x, self.ctx.maxpool2_bwd(x.v, y.g))
+        self.ops.append(bwd)
+        return y
+
+    def backward(self):
+        for op in reversed(self.ops):
+            op()
+        self.ops = []
+
+
+# ----------------------------------------------------------------------------------------------------------------- networks
+def generator_forward(t, x, scale, num_rrdb, attention=True):
+    """ESRGAN_model.py:303-345 on the tape; x Var [B,h,w,3] in [-1,1]."""
+    x = t.conv(x, "initial_conv")
+    trunk = x
+    for b in range(num_rrdb):
+        r_in = x
+        for d in (1, 2, 3):
+            n = f"rrdb_{b}_dense{d}"
+            feats = [x]
+            for k in range(1, 5):
+                feats.append(t.conv(t.cat(feats), f"{n}_conv{k}", act="relu"))
+            x = t.axpby(x, t.conv(t.cat(feats), f"{n}_conv5"), 1.0, 0.2)
+        x = t.axpby(r_in, x, 1.0, 0.2)
+    x = t.axpby(trunk, t.conv(x, "trunk_conv"), 1.0, 1.0)
+    if attention:
+        x = t.attention(x, "self_attention_trunk")
+    s, i = scale, 0
+    while s > 1:
+        x = t.conv(x, f"upsample_{i}_conv", act="lrelu", d2s=2)
+        if i == 0 and attention:
+            x = t.attention(x, "self_attention_upsample_0")
+        s >>= 1
+        i += 1
+    x = t.conv(x, "final_conv1", act="relu")
+    return t.conv(x, "final_conv2", act="tanh")
+
+
+DISC_STRIDES = [1, 2, 1, 2, 1, 2]
+DISC_LAYERS = [f"disc_conv{i}" for i in range(1, 7)] + ["disc_dense1", "disc_output"]
+
+
+def spectral_normalize(kernel, u):
+    """tfa SpectralNormalization.normalize_weights, one power iteration -> (kernel / sigma, new u)."""
+    w = kernel.reshape(-1, kernel.shape[-1]).astype(np.float64)
+    u = u.reshape(1, -1).astype(np.float64)
+    l2n = lambda a: a / np.sqrt(max(float(np.sum(a * a)), 1e-12))
+    v = l2n(u @ w.T)
+    u = l2n(v @ w)
+    sigma = float((v @ w @ u.T).item())
+    return (kernel / np.float32(sigma)).astype(np.float32), u.astype(np.float32)
+
+
+def discriminator_forward(t, x, training, u=None):
+    """ESRGAN_model.py:347-377 on the tape.  training=True first renormalises every stored kernel in place (t.w and u are updated).
+    Returns (probabilities np [B,1], backward(dp) -> None that seeds the tape with d loss / d probabilities)."""
+    ctx = t.ctx
+    if training:
+        for n in DISC_LAYERS:
+            k, nu = spectral_normalize(t.w[n][0], u[n])
+            t.w[n], u[n] = (k, t.w[n][1]), nu
+    h = x
+    for i, st in enumerate(DISC_STRIDES):
+        h = t.conv(h, f"disc_conv{i + 1}", act="lrelu")
+        if st == 2:
+            h = t.pick2(h)
+    B, H, W, C = h.v.shape
+    g = ctx.spatial_op(L.SP_GAP, h.v).cpu().numpy().astype(np.float64)          # [B,256]: the head runs on the host
+    k1, b1 = (a.astype(np.float64) for a in t.w["disc_dense1"])
+    k2, b2 = (a.astype(np.float64) for a in t.w["disc_output"])
+    z1 = g @ k1 + b1
+    a1 = np.where(z1 > 0, z1, 0.2 * z1)
+    z2 = a1 @ k2 + b2
+    p = 1.0 / (1.0 + np.exp(-z2))
+
+    def seed(dp):
+        """dp = d loss / d p  [B,1]."""
+        dz2 = dp * p * (1.0 - p)
+        if t.wgrad:
+            t.grads["disc_output"] = [a1.T @ dz2, dz2.sum(axis=0)]
+        da1 = dz2 @ k2.T
+        dz1 = np.where(z1 > 0, da1, 0.2 * da1)
+        if t.wgrad:
+            t.grads["disc_dense1"] = [g.T @ dz1, dz1.sum(axis=0)]
+        dg = (dz1 @ k1.T) / float(H * W)                                         # GAP backward: spread over the H x W map
+        dgt = ctx.to_device(dg.astype(np.float32))
+        h.g = dgt[:, None, None, :].expand(B, H, W, C).contiguous()
+    return p, seed
+
+
+VGG19_CFG = [(1, 2, 64), (2, 2, 128), (3, 4, 256), (4, 4, 512), (5, 4, 512)]
+
+
+def vgg19_features(t, x):
+    """ESRGAN_model.py:379-408 on the tape (frozen: run it on a Tape with wgrad=False); x Var in [-1,1]."""
+    ctx = t.ctx
+    pre = Var(ctx.spatial_op(L.SP_VGG_PREPROCESS, x.v))
+
+    def bwd():
+        if pre.g is not None and x.need:      # (x+1)*127.5 with RGB -> BGR: the adjoint flips the channels back and scales
+            t._acc(x, ctx.eltwise(L.ELT_AXPBY, torch.flip(pre.g, dims=[-1]).contiguous(), None, 127.5, 0.0))
+    t.ops.append(bwd)
+    h = pre
+    for blk, n, _ in VGG19_CFG:
+        for k in range(1, n + 1):
+            h = t.conv(h, f"block{blk}_conv{k}", act="relu")
+            if (blk, k) == (5, 4):
+                return h
+        h = t.maxpool(h)
+    return h
+
+
+def bce_mean(target, p, eps=1e-7):
+    """mean(keras.backend.binary_crossentropy) on probabilities and its gradient w.r.t. p (clip passes the gradient inside [eps, 1-eps])."""
+    pc = np.clip(p, eps, 1.0 - eps)
+    loss = float(np.mean(-(target * np.log(pc + eps) + (1.0 - target) * np.log(1.0 - pc + eps))))
+    inside = ((p >= eps) & (p <= 1.0 - eps)).astype(np.float64)
+    dp = -(target / (pc + eps) - (1.0 - target) / (1.0 - pc + eps)) * inside / p.size
+    return loss, dp
+
+
+def staircase_lr(lr0, step, decay_steps=10000, decay_rate=0.5):
+    """ExponentialDecay(staircase=True) (ESRGAN_model.py:176-195)."""
+    return lr0 * decay_rate ** (step // decay_steps)
+
+
+# ----------------------------------------------------------------------------------------------------------------- the step
+class ESRGANTrainer:
+    """Holds generator / discriminator / VGG19 weights (host fp32), the SN vectors u, the two Adam states and the step counter."""
+
+    def __init__(self, ctx, g_weights, d_weights, vgg_weights, scale, num_rrdb, attention=True, g_lr=1e-4, d_lr=1e-5, u_seed=0, allreduce=None):
+        self.ctx, self.scale, self.nb, self.att = ctx, scale, num_rrdb, attention
+        self.gw = {n: (np.asarray(k, np.float32), np.asarray(b, np.float32)) for n, (k, b) in g_weights.items()}
+        self.dw = {n: (np.asarray(k, np.float32), np.asarray(b, np.float32)) for n, (k, b) in d_weights.items()}
+        self.vw = vgg_weights
+        rng = np.random.default_rng(u_seed)               # tfa initialises u ~ TruncatedNormal(stddev 0.02), shape [1, Cout]
+        self.u = {n: np.clip(rng.normal(0, 0.02, (1, self.dw[n][0].shape[-1])), -0.04, 0.04).astype(np.float32) for n in DISC_LAYERS}
+        self.g_lr0, self.d_lr0 = g_lr, d_lr
+        self.g_opt, self.d_opt = Adam(self.gw, g_lr, epsilon=1e-7), Adam(self.dw, d_lr, epsilon=1e-7)
+        self.step = 0
+        self.allreduce = allreduce                        # data parallel: callable(dict of host grads) -> averaged dict (RCCL / gloo)
+
+    def _host(self, grads):
+        return {n: (np.asarray(a.cpu().numpy() if isinstance(a, torch.Tensor) else a, np.float32),
+                    np.asarray(b.cpu().numpy() if isinstance(b, torch.Tensor) else b, np.float32)) for n, (a, b) in grads.items()}
+
+    def train_step(self, lr_images, hr_images):
+        """-> {'g_loss', 'd_loss', parts...}; weights, u, optimiser states advance in place (ESRGAN_model.py:475-533)."""
+        ctx = self.ctx
+        lr_t, hr_t = ctx.to_device(np.asarray(lr_images, np.float32)), ctx.to_device(np.asarray(hr_images, np.float32))
+        # ---- discriminator update
+        tg = Tape(ctx, self.gw, wgrad=False)
+        fake = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att).v
+        td = Tape(ctx, self.dw)
+        p_real, seed_real = discriminator_forward(td, Var(hr_t, need=False), True, self.u)       # renormalisation 1
+        l_real, dp = bce_mean(np.ones_like(p_real), p_real)
+        seed_real(dp)
+        td.backward()
+        g_real = self._host(td.grads)
+        td2 = Tape(ctx, self.dw)
+        p_fake, seed_fake = discriminator_forward(td2, Var(fake, need=False), True, self.u)      # renormalisation 2
+        l_fake, dp = bce_mean(np.zeros_like(p_fake), p_fake)
+        seed_fake(dp)
+        td2.backward()
+        g_fake = self._host(td2.grads)
+        d_grads = {n: (g_real[n][0] + g_fake[n][0], g_real[n][1] + g_fake[n][1]) for n in g_real}
+        if self.allreduce is not None:
+            d_grads = self.allreduce(d_grads)
+        self.d_opt.lr = staircase_lr(self.d_lr0, self.step)
+        self.dw = self.d_opt.apply(self.dw, d_grads)
+        # ---- generator update
+        tg = Tape(ctx, self.gw)
+        x = Var(lr_t, need=False)
+        y = generator_forward(tg, x, self.scale, self.nb, self.att)
+        td3 = Tape(ctx, self.dw, wgrad=False)
+        yv = Var(y.v)
+        p, seed = discriminator_forward(td3, yv, True, self.u)                                   # renormalisation 3
+        self.dw = td3.w
+        adv, dp = bce_mean(np.ones_like(p), p)
+        seed(dp)
+        td3.backward()
+        tv = Tape(ctx, self.vw, wgrad=False)
+        fr = vgg19_features(tv, Var(hr_t, need=False))
+        tv.ops = []
+        yv2 = Var(y.v)
+        ff = vgg19_features(tv, yv2)
+        perc = float(ctx.mse(fr.v, ff.v).item())
+        ff.g = ctx.eltwise(L.ELT_AXPBY, ff.v, fr.v, 2.0 / ff.v.numel(), -2.0 / ff.v.numel())
+        tv.backward()
+        pix = float(ctx.l1(hr_t, y.v).item())
+        spec = float(ctx.spectral_l1(y.v, hr_t).item())
+        dy = ctx.eltwise(L.ELT_SIGN_DIFF, y.v, hr_t, 100.0 / y.v.numel(), 0.0)
+        dy = ctx.eltwise(L.ELT_AXPBY, dy, ctx.spectral_l1_bwd(y.v, hr_t, 1.0), 1.0, 1.0)
+        dy = ctx.eltwise(L.ELT_AXPBY, dy, yv.g, 1.0, 1.0)
+        dy = ctx.eltwise(L.ELT_AXPBY, dy, yv2.g, 1.0, 1.0)
+        y.g = dy
+        self.last_dy = dy
+        tg.backward()
+        g_grads = self._host(tg.grads)
+        if self.allreduce is not None:
+            g_grads = self.allreduce(g_grads)
+        self.g_opt.lr = staircase_lr(self.g_lr0, self.step)
+        self.gw = self.g_opt.apply(self.gw, g_grads)
+        self.step += 1
+        self.last_grads = {"g": g_grads, "d": d_grads}
+        return {"g_loss": adv + 1.0 * perc + 100.0 * pix + 1.0 * spec, "d_loss": l_real + l_fake, "adversarial": adv, "perceptual": perc,
+                "pixel": pix, "spectral": spec}

@@ -247,6 +247,67 @@ class Context:
         self.check(self.lib.sr_space_to_depth(self.h, x.data_ptr(), B, Hr // r, Wr // r, Cx, int(r), y.data_ptr(), self.stream()))
         return y
 
+    def spatial_op(self, op, x):
+        """L.SP_MAXPOOL2 / SP_GAP / SP_PICK2 / SP_VGG_PREPROCESS on an fp32 [B,H,W,C] tensor."""
+        _check_tensor(self, x, "spatial op input")
+        B, H, W, Cx = x.shape
+        shape = {L.SP_MAXPOOL2: (B, H // 2, W // 2, Cx), L.SP_GAP: (B, Cx), L.SP_PICK2: (B, (H + 1) // 2, (W + 1) // 2, Cx),
+                 L.SP_VGG_PREPROCESS: (B, H, W, Cx)}[op]
+        y = self.empty(shape, torch.float32)
+        self.check(self.lib.sr_spatial_op(self.h, int(op), x.data_ptr(), B, H, W, Cx, y.data_ptr(), self.stream()))
+        return y
+
+    def matmul(self, a, b, trans_a=False, trans_b=False, alpha=1.0):
+        """Batched fp32 product alpha * op(a) @ op(b): a [batch, M, K] (or [batch, K, M] when trans_a), b likewise."""
+        _check_tensor(self, a, "matmul a")
+        _check_tensor(self, b, "matmul b")
+        if a.dim() != 3 or b.dim() != 3 or a.shape[0] != b.shape[0]:
+            raise ValueError("matmul operands must be [batch, rows, cols] with equal batch")
+        M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+        K2, N = (b.shape[2], b.shape[1]) if trans_b else (b.shape[1], b.shape[2])
+        if K != K2:
+            raise ValueError("matmul inner dimensions differ")
+        c = self.empty((a.shape[0], M, N), torch.float32)
+        self.check(self.lib.sr_matmul(self.h, a.data_ptr(), b.data_ptr(), c.data_ptr(), a.shape[0], M, N, K, int(trans_a), int(trans_b), float(alpha), self.stream()))
+        return c
+
+    def softmax_rows_(self, s):
+        """softmax over the last axis, in place."""
+        _check_tensor(self, s, "softmax input")
+        self.check(self.lib.sr_softmax_rows(self.h, s.data_ptr(), s.numel() // s.shape[-1], s.shape[-1], self.stream()))
+        return s
+
+    def softmax_bwd(self, p, dp):
+        _check_tensor(self, p, "softmax_bwd p")
+        _check_tensor(self, dp, "softmax_bwd dp")
+        ds = torch.empty_like(p)
+        self.check(self.lib.sr_softmax_bwd(self.h, p.data_ptr(), dp.data_ptr(), ds.data_ptr(), p.numel() // p.shape[-1], p.shape[-1], self.stream()))
+        return ds
+
+    def maxpool2_bwd(self, x, dy):
+        _check_tensor(self, x, "maxpool_bwd x")
+        _check_tensor(self, dy, "maxpool_bwd dy")
+        B, H, W, Cx = x.shape
+        dx = torch.empty_like(x)
+        self.check(self.lib.sr_maxpool2_bwd(self.h, x.data_ptr(), dy.data_ptr(), B, H, W, Cx, dx.data_ptr(), self.stream()))
+        return dx
+
+    def zero_insert2(self, dy, H, W):
+        """Adjoint of SP_PICK2: dy [B,ceil(H/2),ceil(W/2),C] -> [B,H,W,C]."""
+        _check_tensor(self, dy, "zero_insert dy")
+        B, _, _, Cx = dy.shape
+        out = self.empty((B, H, W, Cx), torch.float32)
+        self.check(self.lib.sr_zero_insert2(self.h, dy.data_ptr(), B, int(H), int(W), Cx, out.data_ptr(), self.stream()))
+        return out
+
+    def spectral_l1_bwd(self, a, b, scale=1.0):
+        _check_tensor(self, a, "spectral_bwd a")
+        _check_tensor(self, b, "spectral_bwd b")
+        B, H, W, Cx = a.shape
+        da = torch.empty_like(a)
+        self.check(self.lib.sr_spectral_l1_bwd(self.h, a.data_ptr(), b.data_ptr(), B, H, W, Cx, float(scale), da.data_ptr(), self.stream()))
+        return da
+
     def l1(self, a, b):
         """mean |a - b| (ESRGAN _pixel_loss) -> [1] tensor."""
         _check_tensor(self, a, "l1 input a")

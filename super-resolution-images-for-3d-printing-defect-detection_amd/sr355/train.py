@@ -36,6 +36,9 @@ class Adam:
         lr_t = np.float32(self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t))
         out = {}
         for n, (k, b) in weights.items():
+            if n not in grads:                                     # a variable the loss does not reach: Keras skips None gradients
+                out[n] = (k, b)
+                continue
             new = []
             for slot, (var, g) in enumerate(((k, grads[n][0]), (b, grads[n][1]))):
                 g = np.asarray(g, np.float32)

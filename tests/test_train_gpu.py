@@ -150,3 +150,101 @@ def test_edsr_fit_wrapper(ctx):
     assert h["loss"][-1] < h["loss"][0] and len(tcb.epoch_times_sec) == len(h["loss"])
     sr, _ = m.super_resolve_image(lr[0], patch_size_lr=12, stride=6)
     assert sr.shape == (24, 24, 3)
+
+
+# ------------------------------------------------------------------------------------------------ ESRGAN._train_step (BASELINE configs[3])
+def _gan_setup(scale, nb, G, seed=0):
+    gw = init_weights(M.esrgan_g_layers(scale, G, nb), seed=3000)
+    gw = {n: ((k * 0.25, b * 0.25) if (n.endswith("_f") or n.endswith("_g")) else (k, b)) for n, (k, b) in gw.items()}     # moderate attention logits
+    dw = init_weights(M.discriminator_layers(), seed=5000)
+    vw = init_weights(M.vgg19_extractor_layers(), scheme="he_normal", seed=6000)
+    vw = {n: (k * 0.05 if n == "block1_conv1" else k, b) for n, (k, b) in vw.items()}          # inputs are +-128 after caffe preprocessing: keep the features O(1)
+    return gw, dw, vw
+
+
+def test_attention_forward_backward_materialised(ctx):
+    from sr355 import gan_train as GT
+    rng = np.random.default_rng(4)
+    w = init_weights(M.self_attention_layers("sa"), seed=9)
+    x = (0.5 * rng.standard_normal((2, 6, 5, 64))).astype(np.float32)
+    dy = rng.standard_normal((2, 6, 5, 64)).astype(np.float32)
+    t = GT.Tape(ctx, w)
+    xv = GT.Var(ctx.to_device(x))
+    y = t.attention(xv, "sa")
+    assert rel_l2(y.v.cpu().numpy(), O.self_attention(x, *w["sa_f"], *w["sa_g"], *w["sa_h"], *w["sa_v"], dtype=np.float64)) <= 1e-5
+    y.g = ctx.to_device(dy)
+    t.backward()
+    p = OT._params(w)
+    xt = torch.tensor(x.astype(np.float64)).permute(0, 3, 1, 2).requires_grad_(True)
+    OT._sa_t(p, xt, "sa").backward(torch.tensor(dy.astype(np.float64)).permute(0, 3, 1, 2))
+    assert rel_l2(xv.g.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy()) <= 2e-5
+    for n in w:
+        assert rel_l2(t.grads[n][0].cpu().numpy(), p[n][0].grad.numpy()) <= 5e-5, n
+        if n.endswith("_f"):       # a key bias shifts every score of a row by the same amount: softmax ignores it, the gradient is exactly zero
+            assert np.abs(t.grads[n][1].cpu().numpy()).max() <= 1e-5
+        else:
+            assert rel_l2(t.grads[n][1].cpu().numpy(), p[n][1].grad.numpy()) <= 5e-5, n
+
+
+def test_spectral_loss_gradient_and_pool_adjoints(ctx):
+    rng = np.random.default_rng(6)
+    a = rng.uniform(-1, 1, (2, 5, 24, 3)).astype(np.float32)
+    b = rng.uniform(-1, 1, (2, 5, 24, 3)).astype(np.float32)
+    at = torch.tensor(a.astype(np.float64), requires_grad=True)
+    loss = torch.mean(torch.abs(torch.abs(torch.fft.fft2(at.to(torch.complex128))) - torch.abs(torch.fft.fft2(torch.tensor(b.astype(np.float64)).to(torch.complex128)))))
+    loss.backward()
+    got = ctx.spectral_l1_bwd(ctx.to_device(a), ctx.to_device(b), 1.0).cpu().numpy()
+    assert rel_l2(got, at.grad.numpy()) <= 2e-4, rel_l2(got, at.grad.numpy())
+    # maxpool backward and the stride-2 pick's adjoint against autograd
+    x = rng.standard_normal((2, 8, 6, 5)).astype(np.float32)
+    dy = rng.standard_normal((2, 4, 3, 5)).astype(np.float32)
+    xt = torch.tensor(x.astype(np.float64)).permute(0, 3, 1, 2).requires_grad_(True)
+    F = torch.nn.functional
+    F.max_pool2d(xt, 2).backward(torch.tensor(dy.astype(np.float64)).permute(0, 3, 1, 2))
+    assert np.allclose(ctx.maxpool2_bwd(ctx.to_device(x), ctx.to_device(dy)).cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), atol=1e-6)
+    for hw in ((8, 6), (7, 5)):
+        z = rng.standard_normal((2, hw[0], hw[1], 3)).astype(np.float32)
+        pick = ctx.spatial_op(L.SP_PICK2, ctx.to_device(z))
+        g = rng.standard_normal(tuple(pick.shape)).astype(np.float32)
+        back = ctx.zero_insert2(ctx.to_device(g), hw[0], hw[1]).cpu().numpy()
+        assert abs(float((back * z).sum()) - float((g * pick.cpu().numpy()).sum())) <= 1e-4        # <A^T g, z> == <g, A z>
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, 8, True), (4, 1, 32, True), (2, 2, 8, False)])
+def test_esrgan_train_step(ctx, cfg):
+    """One _train_step against the torch-autograd restatement: the six loss terms, every generator and discriminator gradient,
+    the updated weights, and the discriminator kernels after their three in-place spectral renormalisations."""
+    from sr355 import gan_train as GT
+    scale, nb, G, att = cfg
+    gw, dw, vw = _gan_setup(scale, nb, G)
+    rng = np.random.default_rng(7)
+    lr = rng.uniform(-1, 1, (2, 12, 12, 3)).astype(np.float32)
+    hr = rng.uniform(-1, 1, (2, 12 * scale, 12 * scale, 3)).astype(np.float32)
+    tr = GT.ESRGANTrainer(ctx, gw, dw, vw, scale, nb, attention=att, g_lr=1e-4, d_lr=1e-5, u_seed=3)
+    u0 = {n: v.copy() for n, v in tr.u.items()}
+    out = tr.train_step(lr, hr)
+    ref = OT.esrgan_train_step_ref(gw, dw, u0, vw, lr, hr, scale, nb, attention=att)
+    for k, v in ref["losses"].items():
+        assert abs(out[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, out[k], v)
+    for n, (rk, rb) in ref["d_grads"].items():
+        assert rel_l2(tr.last_grads["d"][n][0], rk) <= 2e-4, ("d", n, rel_l2(tr.last_grads["d"][n][0], rk))
+        assert rel_l2(tr.last_grads["d"][n][1], rb) <= 2e-4, ("d bias", n)
+    # d g_loss / d G(lr): the loss networks have kinks (VGG's ReLUs and max-pools, |.| of the pixel term), and the two G(lr) differ in
+    # their last bits, so a handful of pixels may sit on different branches; everywhere else the gradient agrees tightly.
+    dy = tr.last_dy.cpu().numpy().astype(np.float64)
+    off = np.abs(dy - ref["dy"]) > 1e-5 * np.abs(ref["dy"]).max()
+    assert off.mean() <= 0.01, off.mean()
+    assert rel_l2(np.where(off, 0, dy), np.where(off, 0, ref["dy"])) <= 1e-4
+    # ... and the generator's backward pass is checked on one common dy (the device's), so that its tolerance stays tight.
+    ref = OT.esrgan_train_step_ref(gw, dw, u0, vw, lr, hr, scale, nb, attention=att, dy_override=dy)
+    assert set(tr.last_grads["g"]) == set(ref["g_grads"])
+    errs = sorted(((rel_l2(tr.last_grads["g"][n][0], ref["g_grads"][n][0]), n) for n in ref["g_grads"]), reverse=True)
+    assert errs[0][0] <= 2e-4, errs[:3]
+    berrs = sorted(((float(np.abs(tr.last_grads["g"][n][1] - ref["g_grads"][n][1]).max() / max(np.abs(ref["g_grads"][n][1]).max(), 1e-3)), n)
+                    for n in ref["g_grads"]), reverse=True)
+    assert berrs[0][0] <= 2e-4, berrs[:3]
+    for n in ref["dw"]:        # kernels after Adam and the third renormalisation, and the power-iteration vectors
+        assert rel_l2(tr.dw[n][0], ref["dw"][n][0]) <= 1e-5 and rel_l2(tr.u[n], ref["u"][n]) <= 1e-5, n
+    for n in ref["gw"]:
+        assert rel_l2(tr.gw[n][0] - gw[n][0], ref["gw"][n][0] - gw[n][0]) <= 5e-3, n
+    assert tr.step == 1 and GT.staircase_lr(1e-4, 9999) == 1e-4 and GT.staircase_lr(1e-4, 10000) == 5e-5
