@@ -6,14 +6,15 @@ trunk conv + skip, SelfAttention, log2(scale) x (conv64->256, depth_to_space, Le
 SelfAttention after the first), conv64 ReLU, conv->3 tanh.
 Discriminator (:347-377) and VGG19 perceptual extractor (:379-408) exist as inference graphs: together with the loss kernels
 (pixel L1, FFT-(W,C) spectral L1, MSE of VGG19 features; BCE on the [B,1] discriminator output) they give the generator loss that
-`evaluate` reports as avg_g_loss (:782-856).  The GAN training loop itself (_train_step :475-533: backward passes, spectral-norm
-updates, Adam) is the next row and is not built.
+`evaluate` reports as avg_g_loss (:782-856).  The GAN training loop (_train_step :475-533, fit :535-779) runs on sr355.gan_train's
+ESRGANTrainer in fp32: backward passes through the C ABI's ops, in-place spectral-norm updates, two Adams with staircase decay.
 """
 import os
 
 import numpy as np
 import torch
 
+from sr355 import _lib as L
 from sr355 import pipeline as P
 from sr355.wrappers import DeviceModelMixin, load_pretrained
 
@@ -42,6 +43,7 @@ class ESRGAN(DeviceModelMixin):
             weights = load_pretrained(generator_pretrained_path)
             growth_channels = int(weights["rrdb_0_dense1_conv1"][0].shape[-1]) if "rrdb_0_dense1_conv1" in weights else growth_channels
             num_rrdb_blocks = len({n.split("_")[1] for n in weights if n.startswith("rrdb_")})
+        self.num_rrdb_blocks, self.use_attention, self._trainer = int(num_rrdb_blocks), bool(use_attention), None
         self.generator = self._make("esrgan_g", self.compute_dtype, scale_factor=scale_factor, channels=int(input_shape[-1]),
                                     num_blocks=num_rrdb_blocks, growth_channels=growth_channels, use_attention=use_attention)
         if weights is not None:
@@ -81,6 +83,12 @@ class ESRGAN(DeviceModelMixin):
         if vgg19 is not None:
             self.vgg_weights = {n: (np.asarray(k, np.float32), np.asarray(b, np.float32)) for n, (k, b) in vgg19.items()}
             self.vgg_model = None
+        tr = getattr(self, "_trainer", None)
+        if tr is not None:                                 # a live trainer follows (its Adam moments and u vectors stay)
+            if discriminator is not None and tr.dw is not discriminator:
+                tr.dw = dict(self.d_weights)
+            if vgg19 is not None:
+                tr.vw = self.vgg_weights
 
     def generator_loss(self, hr_real, hr_fake):
         """g_loss of _train_step / evaluate for given generator output (ESRGAN_model.py:511-523, :812-826), on the device:
@@ -99,10 +107,160 @@ class ESRGAN(DeviceModelMixin):
         parts = {"adversarial": adv, "perceptual": perc, "pixel": pix, "spectral": spec}
         return adv + 1.0 * perc + 100.0 * pix + 1.0 * spec, parts
 
-    def fit(self, *args, **kwargs):
-        raise NotImplementedError("ESRGAN adversarial training (_train_step: backward passes, spectral-norm updates, Adam) is the next row "
-                                  "(SURVEY.md 8f-1); its forward halves -- discriminator, VGG19 extractor, the four loss terms -- are "
-                                  "built: see generator_loss()")
+    def _ensure_trainer(self):
+        """The optimisers live from setup_model on in the reference (ESRGAN_model.py:176-195): one trainer (weights, Adam moments,
+        spectral-norm vectors, step counter) per model, kept across fit() calls."""
+        from sr355.gan_train import ESRGANTrainer
+        if getattr(self, "_trainer", None) is None:
+            self._ensure_loss_networks()
+            self._trainer = ESRGANTrainer(self.ctx, self.weights, self.d_weights, self.vgg_weights, self.scale_factor,
+                                          self.num_rrdb_blocks, attention=self.use_attention, g_lr=1e-4, d_lr=1e-5,
+                                          allreduce=getattr(self, "grad_allreduce", None))
+            self.g_optimizer, self.d_optimizer = self._trainer.g_opt, self._trainer.d_opt
+        return self._trainer
+
+    def _sync_from_trainer(self):
+        tr = self._trainer
+        self.set_weights(tr.gw)
+        self.set_loss_network_weights(discriminator=tr.dw)
+
+    def _train_step(self, lr_batch, hr_batch):
+        """ESRGAN_model.py:475-533 on [-1,1] batches -> {'g_loss', 'd_loss', ...} (floats)."""
+        return self._ensure_trainer().train_step(lr_batch, hr_batch)
+
+    def fit(self, X_train=None, Y_train=None, train_dataset=None, X_val=None, Y_val=None, val_dataset=None, epochs=100, batch_size=16,
+            steps_per_epoch=None, val_steps=None, normalize=True, save_dir=None, shuffle_seed=42):
+        """ESRGAN.fit (ESRGAN_model.py:535-779).  (X_train, Y_train) arrays in [0,1] -- reshuffled every epoch, batched, last batch
+        partial -- or `train_dataset`, a re-iterable of (lr, hr) batches that is cycled (steps_per_epoch then mandatory).  Per step:
+        _train_step, then PSNR / SSIM of generator(lr, training=False) against hr in [0,1], and the two decayed learning rates.
+        Validation (arrays or an iterable of batches) reports the generator loss with the discriminator / VGG19 at inference.
+        With save_dir a 5x5 grid of generator outputs is written per epoch.  Returns (epoch_losses of the LAST epoch -- per-step lists,
+        val_* scalars -- as the reference does, EpochTimeTracker, EpochMemoryTracker)."""
+        from sr355.gan_train import Tape, Var, generator_forward, staircase_lr
+        from sr355.train import EpochMemoryTracker, EpochTimeTracker
+        if train_dataset is None and (X_train is None or Y_train is None):
+            raise ValueError("Debe aportar (X_train,Y_train) o un train_dataset")
+        if self.generator is None:
+            raise RuntimeError("Generator is not initialized.")
+        if train_dataset is not None and steps_per_epoch is None:
+            raise ValueError("Debe indicar steps_per_epoch cuando aporta un dataset externo")
+        print("Training on GPU:", [f"MI355X:{self.ctx.device}"])
+        tr = self._ensure_trainer()
+        rng = np.random.default_rng(shuffle_seed)
+        norm = (lambda a: np.asarray(a, np.float32) * 2.0 - 1.0) if normalize else (lambda a: np.asarray(a, np.float32))
+        if train_dataset is None:
+            X_train, Y_train = np.asarray(X_train, np.float32), np.asarray(Y_train, np.float32)
+            if steps_per_epoch is None:
+                steps_per_epoch = int(np.ceil(len(X_train) / batch_size))
+
+            def batches():                                  # from_tensor_slices().shuffle(len).batch(bs).repeat()
+                while True:
+                    order = rng.permutation(len(X_train))
+                    for i in range(0, len(order), batch_size):
+                        yield X_train[order[i:i + batch_size]], Y_train[order[i:i + batch_size]]
+        else:
+            def batches():                                  # dataset.repeat()
+                while True:
+                    n = 0
+                    for pair in train_dataset:
+                        n += 1
+                        yield pair
+                    if n == 0:
+                        raise RuntimeError("train_dataset produced no batches")
+        stream = batches()
+        if val_dataset is not None:
+            val_batches = lambda: iter(val_dataset)
+        elif X_val is not None and Y_val is not None:
+            X_val, Y_val = np.asarray(X_val, np.float32), np.asarray(Y_val, np.float32)
+            val_batches = lambda: ((X_val[i:i + batch_size], Y_val[i:i + batch_size]) for i in range(0, len(X_val), batch_size))
+            if val_steps is None:
+                val_steps = int(np.ceil(len(X_val) / batch_size))
+        else:
+            val_batches = None
+        if save_dir is not None:
+            os.makedirs(save_dir, exist_ok=True)
+        preview = None                                      # (lr batch, already normalised?) fixed across epochs (:616-646)
+
+        def generate_f32(lr_pm1):
+            t = Tape(self.ctx, tr.gw, wgrad=False)
+            out = generator_forward(t, Var(self.ctx.to_device(np.asarray(lr_pm1, np.float32)), need=False), tr.scale, tr.nb, tr.att).v
+            t.ops = []
+            return out
+
+        def to01(t):                                       # (x + 1) / 2
+            return self.ctx.eltwise(L.ELT_AXPBY, t, torch.ones_like(t), 0.5, 0.5)
+
+        def save_grid(epoch_idx):
+            nonlocal preview
+            if save_dir is None:
+                return
+            if preview is None:
+                if X_val is not None and len(X_val) > 0:
+                    preview = (np.asarray(X_val[:25], np.float32), False)
+                elif X_train is not None and len(X_train) > 0:
+                    preview = (np.asarray(X_train[:25], np.float32), False)
+                else:
+                    src = val_batches() if val_batches is not None else iter(train_dataset)
+                    first = next(src, None)
+                    if first is None:
+                        raise RuntimeError("No se pudo obtener un batch de previsualización para guardar imágenes.")
+                    preview = (norm(first[0])[:25], True)
+            lr_p, is_norm = preview
+            sr = (generate_f32(lr_p if is_norm else lr_p * 2.0 - 1.0).cpu().numpy() + 1.0) / 2.0
+            n, (h, w, ch) = min(25, sr.shape[0]), sr.shape[1:]
+            grid = np.zeros((5 * h, 5 * w, ch), np.uint8)
+            for idx in range(n):
+                r, c = divmod(idx, 5)
+                grid[r * h:(r + 1) * h, c * w:(c + 1) * w] = (np.clip(sr[idx], 0.0, 1.0) * 255.0).round().astype(np.uint8)
+            from PIL import Image
+            Image.fromarray(grid if ch != 1 else grid[..., 0]).save(os.path.join(save_dir, f"epoch_{epoch_idx:03d}_sr_grid.png"))
+
+        time_tracker, memory_tracker = EpochTimeTracker(), EpochMemoryTracker(self.ctx)
+        epoch_losses = {}
+        for epoch in range(epochs):
+            print(f"Epoch {epoch + 1}/{epochs}")
+            time_tracker.begin_epoch()
+            memory_tracker.begin_epoch()
+            epoch_losses = {k: [] for k in ("g_loss", "val_g_loss", "d_loss", "psnr", "val_psnr", "ssim", "val_ssim", "g_lr", "d_lr")}
+            for step in range(steps_per_epoch):
+                lr_b, hr_b = next(stream)
+                lr_b, hr_b = norm(lr_b), norm(hr_b)
+                losses = tr.train_step(lr_b, hr_b)
+                epoch_losses["g_loss"].append(float(losses["g_loss"]))
+                epoch_losses["d_loss"].append(float(losses["d_loss"]))
+                gen01 = to01(generate_f32(lr_b))
+                real01 = self.ctx.to_device((hr_b + 1.0) / 2.0)
+                epoch_losses["psnr"].append(float(self.ctx.psnr(real01, gen01).mean().item()))
+                epoch_losses["ssim"].append(float(self.ctx.ssim(real01, gen01).mean().item()))
+                epoch_losses["g_lr"].append(float(np.float32(staircase_lr(tr.g_lr0, tr.step))))
+                epoch_losses["d_lr"].append(float(np.float32(staircase_lr(tr.d_lr0, tr.step))))
+                if (step + 1) % 10 == 0 or (step + 1) == steps_per_epoch:
+                    print(f"  Step {step + 1}/{steps_per_epoch} G_loss={epoch_losses['g_loss'][-1]:.4f} "
+                          f"D_loss={epoch_losses['d_loss'][-1]:.4f} PSNR={epoch_losses['psnr'][-1]:.2f} SSIM={epoch_losses['ssim'][-1]:.4f}")
+            print(f"- Epoch Summary - G_loss: {np.mean(epoch_losses['g_loss']):.4f}, D_loss: {np.mean(epoch_losses['d_loss']):.4f}, "
+                  f"PSNR: {np.mean(epoch_losses['psnr']):.2f}, SSIM: {np.mean(epoch_losses['ssim']):.4f}")
+            if val_batches is not None:
+                self.set_loss_network_weights(discriminator=tr.dw)
+                vp, vs, vg = [], [], []
+                for i, (lr_v, hr_v) in enumerate(val_batches()):
+                    if val_steps is not None and i >= val_steps:
+                        break
+                    lr_v, hr_v = norm(lr_v), norm(hr_v)
+                    fake, real = generate_f32(lr_v), self.ctx.to_device(hr_v)
+                    vg.append(float(self.generator_loss(real, fake)[0]))
+                    g01, r01 = to01(fake), to01(real)
+                    vp.append(float(self.ctx.psnr(r01, g01).mean().item()))
+                    vs.append(float(self.ctx.ssim(r01, g01).mean().item()))
+                nanmean = lambda v: float(np.mean(v)) if len(v) > 0 else float("nan")
+                epoch_losses["val_psnr"], epoch_losses["val_ssim"], epoch_losses["val_g_loss"] = nanmean(vp), nanmean(vs), nanmean(vg)
+                print(f"  Validation -> PSNR: {epoch_losses['val_psnr']:.2f}, SSIM: {epoch_losses['val_ssim']:.4f}, "
+                      f"G_loss: {epoch_losses['val_g_loss']:.4f}")
+            save_grid(epoch + 1)
+            self.trained = True
+            memory_tracker.end_epoch()
+            time_tracker.end_epoch()
+        self._sync_from_trainer()
+        return epoch_losses, time_tracker, memory_tracker
 
     def generate(self, lr_batch):
         """generator(lr, training=False) on a [-1,1] batch (ESRGAN_model.py:810); NumPy or device tensor."""

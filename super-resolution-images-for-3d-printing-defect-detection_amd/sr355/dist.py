@@ -65,6 +65,32 @@ def allreduce_max(t):
     return _allreduce(t, dist.ReduceOp.MAX)
 
 
+def allreduce_mean_grads(grads, device=None):
+    """Data-parallel training (ESRGANTrainer's `allreduce` hook, sr355.train.fit): {layer: (dk, db)} host arrays of this rank's
+    batch shard -> the mean over ranks, same structure.  All layers travel as ONE flat fp32 bucket (a full ESRGAN generator is
+    ~67 MB: one ring all-reduce at xGMI link rate, not hundreds of latency-bound small ones); under RCCL the bucket is reduced on
+    `device`, under gloo on the host.  Equal shard sizes make the mean of the per-rank batch-mean gradients the full-batch gradient."""
+    import numpy as np
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return grads
+    names = sorted(grads)
+    parts = [np.asarray(a, np.float32).ravel() for n in names for a in grads[n]]
+    flat = torch.from_numpy(np.concatenate(parts))
+    if dist.get_backend() == "nccl":
+        flat = flat.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat = (flat / dist.get_world_size()).cpu().numpy()
+    out, o = {}, 0
+    for n in names:
+        pair = []
+        for a in grads[n]:
+            a = np.asarray(a)
+            pair.append(flat[o:o + a.size].reshape(a.shape).copy())
+            o += a.size
+        out[n] = tuple(pair)
+    return out
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -140,6 +140,40 @@ class EpochMemoryRecord:
         self.gpu_mean_current_mb = []
         self.gpu_peak_mb = []
 
+    def as_dict(self):
+        return {"gpu_mean_current_mb": float(np.mean(self.gpu_mean_current_mb)), "gpu_peak_mb": float(np.max(self.gpu_peak_mb))}
+
+
+class EpochTimeTracker(EpochTimeRecord):
+    """Manual tracker of the custom ESRGAN loop (callbacks.py:104-121)."""
+    def __init__(self):
+        super().__init__()
+        self._t0 = None
+
+    def begin_epoch(self):
+        self._t0 = time.perf_counter()
+
+    def end_epoch(self):
+        if self._t0 is not None:
+            self.epoch_times_sec.append(time.perf_counter() - self._t0)
+            self._t0 = None
+
+
+class EpochMemoryTracker(EpochMemoryRecord):
+    """callbacks.py:123-176 with libsr355's allocator counters in place of tf.config.experimental.get_memory_info."""
+    def __init__(self, ctx):
+        super().__init__()
+        self.ctx, self._begin = ctx, None
+
+    def begin_epoch(self):
+        self._begin = self.ctx.mem_info()
+
+    def end_epoch(self):
+        end, begin = self.ctx.mem_info(), self._begin or self.ctx.mem_info()
+        self.gpu_mean_current_mb.append((begin["current"] + end["current"]) / 2.0 / (1024.0 * 1024.0))
+        self.gpu_peak_mb.append(max(begin["peak"], end["peak"]) / (1024.0 * 1024.0))
+        self._begin = None
+
 
 def fit(ctx, weights, loss_and_grads, predict, optimizer, X_train, Y_train, X_val, Y_val, batch_size=16, epochs=50, es_patience=3,
         lr_patience=2, lr_factor=0.5, min_lr=1e-7, shuffle=True, seed=42, verbose=True):

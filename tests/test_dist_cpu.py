@@ -75,3 +75,60 @@ def test_two_rank_metric_allreduce():
     assert got["n"] == n and tmax == 2.0
     assert abs(got["psnr"] - O.psnr(a, b, dtype=np.float64).mean()) < 1e-9
     assert abs(got["ssim"] - O.ssim(a, b, dtype=np.float64).mean()) < 1e-9
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from oracle import models as M, train as OT
+    from sr355 import dist as D
+    from sr355.weights import init_weights
+    r, w, _ = D.init_from_env(backend="gloo")
+    wts = init_weights(M.srcnn_layers(), seed=11)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 1, (4, 12, 12, 3)).astype(np.float32)
+    t = rng.uniform(0, 1, (4, 12, 12, 3)).astype(np.float32)
+    lo, hi = D.shard_range(4, r, w)
+    opt = OT.AdamRef(wts, 1e-3)
+    w64 = {n: (np.asarray(k, np.float64), np.asarray(b, np.float64)) for n, (k, b) in wts.items()}
+    for _ in range(2):                                   # two steps: the ranks must stay bit-identical to each other
+        _, _, g = OT.loss_and_grads(OT.srcnn_forward_t, w64, x[lo:hi], t[lo:hi])
+        g = D.allreduce_mean_grads(g)
+        w64 = opt.apply(w64, g)
+    flat = torch.from_numpy(np.concatenate([np.asarray(a, np.float64).ravel() for n in sorted(w64) for a in w64[n]]))
+    other = flat.clone()
+    D.allreduce_max(other)
+    assert torch.equal(other, flat)                      # max over ranks == own value on every rank: replicas agree exactly
+    if rank == 0:
+        q.put(flat.numpy())
+    D.shutdown()
+
+
+def test_two_rank_data_parallel_gradients():
+    """Training shards the batch over the ranks and averages the gradients in one flat bucket (sr355.dist.allreduce_mean_grads):
+    two gloo ranks with half a batch each take the same Adam steps as one process with the whole batch."""
+    from oracle import models as M, train as OT
+    from sr355.weights import init_weights
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import time
+    t0 = time.time()
+    while q.empty() and time.time() - t0 < 180 and all(p.exitcode in (None, 0) for p in procs):
+        time.sleep(0.2)
+    assert not q.empty(), [p.exitcode for p in procs]
+    got = q.get()                                        # read before join: the weights do not fit the pipe's buffer
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    wts = init_weights(M.srcnn_layers(), seed=11)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 1, (4, 12, 12, 3)).astype(np.float32)
+    t = rng.uniform(0, 1, (4, 12, 12, 3)).astype(np.float32)
+    ref, _ = OT.train_steps(OT.srcnn_forward_t, wts, [(x, t), (x, t)], 1e-3)
+    flat = np.concatenate([np.asarray(a, np.float64).ravel() for n in sorted(ref) for a in ref[n]])
+    # the bucket travels in fp32: the averaged gradient carries fp32 rounding, Adam's first steps are ~lr * sign(g)
+    assert np.abs(got - flat).max() <= 2e-5
+    assert np.abs(got - np.concatenate([np.asarray(a, np.float64).ravel() for n in sorted(wts) for a in wts[n]])).max() > 5e-4   # it moved

@@ -248,3 +248,55 @@ def test_esrgan_train_step(ctx, cfg):
     for n in ref["gw"]:
         assert rel_l2(tr.gw[n][0] - gw[n][0], ref["gw"][n][0] - gw[n][0]) <= 5e-3, n
     assert tr.step == 1 and GT.staircase_lr(1e-4, 9999) == 1e-4 and GT.staircase_lr(1e-4, 10000) == 5e-5
+
+
+def test_esrgan_fit_wrapper(ctx, tmp_path):
+    """ESRGAN.fit (ESRGAN_model.py:535-779): arrays in [0,1] -> shuffled batches in [-1,1] -> _train_step per batch; the returned
+    record is the last epoch's; the first step of the first epoch is checked against the oracle's step on the same batch."""
+    from PIL import Image
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    m = ESRGAN(compute_dtype="f32")
+    m.setup_model(scale_factor=2, growth_channels=8, num_rrdb_blocks=1, use_attention=True)
+    with pytest.raises(ValueError):
+        m.fit()
+    with pytest.raises(ValueError):
+        m.fit(train_dataset=[(np.zeros((1, 8, 8, 3)), np.zeros((1, 16, 16, 3)))])            # steps_per_epoch is mandatory here
+    _, dw, vw = _gan_setup(2, 1, 8)
+    m.set_loss_network_weights(discriminator=dw, vgg19=vw)
+    gw0 = {n: (k.copy(), b.copy()) for n, (k, b) in m.weights.items()}
+    rng = np.random.default_rng(12)
+    X, Y = rng.uniform(0, 1, (6, 12, 12, 3)).astype(np.float32), rng.uniform(0, 1, (6, 24, 24, 3)).astype(np.float32)
+    Xv, Yv = rng.uniform(0, 1, (3, 12, 12, 3)).astype(np.float32), rng.uniform(0, 1, (3, 24, 24, 3)).astype(np.float32)
+    save_dir = str(tmp_path / "grids")
+    # one epoch first, so that the first step is observable ...
+    losses, tt, mt = m.fit(X, Y, X_val=Xv, Y_val=Yv, epochs=1, batch_size=4, save_dir=save_dir, shuffle_seed=42)
+    assert m.trained and len(losses["g_loss"]) == 2 == len(losses["d_loss"]) == len(losses["psnr"]) == len(losses["ssim"])
+    order = np.random.default_rng(42).permutation(6)
+    tr = m._trainer
+    u0 = None                                            # the trainer drew its u with seed 0: rebuild it the same way
+    from sr355 import gan_train as GT
+    u0 = GT.ESRGANTrainer(ctx, gw0, dw, vw, 2, 1, u_seed=0).u
+    ref = OT.esrgan_train_step_ref(gw0, dw, u0, vw, X[order[:4]] * 2 - 1, Y[order[:4]] * 2 - 1, 2, 1, attention=True)
+    assert abs(losses["g_loss"][0] - ref["losses"]["g_loss"]) <= 2e-4 * abs(ref["losses"]["g_loss"])
+    assert abs(losses["d_loss"][0] - ref["losses"]["d_loss"]) <= 2e-4
+    assert losses["g_lr"] == [float(np.float32(1e-4))] * 2 and losses["d_lr"] == [float(np.float32(1e-5))] * 2
+    for k in ("val_psnr", "val_ssim", "val_g_loss"):
+        assert isinstance(losses[k], float) and np.isfinite(losses[k])
+    # validation g_loss is the evaluate() formula on the validation batches with the trained networks
+    ev = m.evaluate([(Xv * 2 - 1, Yv * 2 - 1)])
+    assert abs(ev["avg_g_loss"] - losses["val_g_loss"]) <= 1e-3 * abs(losses["val_g_loss"])
+    assert abs(ev["avg_psnr"] - losses["val_psnr"]) <= 1e-3
+    grid = np.asarray(Image.open(f"{save_dir}/epoch_001_sr_grid.png"))
+    assert grid.shape == (5 * 24, 5 * 24, 3) and grid[:24, :72].any() and not grid[24:].any()     # 3 validation previews, the rest black
+    assert len(tt.epoch_times_sec) == 1 and tt.mean_time_value() > 0 and len(mt.gpu_peak_mb) == 1 and mt.as_dict()["gpu_peak_mb"] > 0
+    # ... then two more through an external, already normalised dataset: the optimiser state carries on (step counter 2 -> 6)
+    ds = [(X[:3] * 2 - 1, Y[:3] * 2 - 1), (X[3:] * 2 - 1, Y[3:] * 2 - 1)]
+    losses2, tt2, _ = m.fit(train_dataset=ds, epochs=2, steps_per_epoch=2, normalize=False)
+    assert tr is m._trainer and tr.step == 6 and len(tt2.epoch_times_sec) == 2
+    assert losses2["val_g_loss"] == [] and len(losses2["g_loss"]) == 2
+    moved = max(float(np.abs(m.weights[n][0] - gw0[n][0]).max()) for n in gw0)
+    assert 1e-4 < moved < 1e-2                           # six Adam steps of 1e-4
+    sr = m.generate(X[:2] * 2 - 1)                       # the inference model carries the trained weights
+    t = GT.Tape(ctx, tr.gw, wgrad=False)
+    want = GT.generator_forward(t, GT.Var(ctx.to_device(X[:2] * 2 - 1), need=False), 2, 1, True).v.cpu().numpy()
+    assert rel_l2(np.asarray(sr.cpu() if isinstance(sr, torch.Tensor) else sr), want) <= 1e-5
