@@ -160,6 +160,22 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
             case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+            case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+            case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+            case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+            case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+            case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than the table covers: wait for everything (slower, never wrong)
         }
     };
@@ -314,7 +330,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     // publishes everybody's pieces; then its share of the weights two granules ahead.
     int s2w = 0, i2w = 1, mine = 0;
     auto sync = [&]() {
-        wait_all_but(mine);
+        if (WCOMP > 0) wait_all_but(mine);   // only the DMA pieces a compute wave issued itself need its vmcnt; its epilogue stores drain on their own
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         next_pos(s2w, i2w);
