@@ -11,6 +11,7 @@
 //     the 1x1 "v" conv with the residual add in its epilogue.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <memory>
@@ -491,6 +492,8 @@ int sr_measure_clock(sr_ctx* ctx, float* mhz, void* stream) {
 int sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer) {
     if (!ctx) return SR_ERR_INVALID;
     ctx->chain_stamp_buf = static_cast<unsigned long long*>(device_u64_buffer);
+    const char* skip = getenv("SR355_CHAIN_STAMP_SKIP");
+    ctx->chain_stamp_skip = skip ? atoi(skip) : -1;
     return SR_OK;
 }
 

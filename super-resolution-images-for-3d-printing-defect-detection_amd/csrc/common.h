@@ -29,6 +29,7 @@ struct sr_ctx {
     void* scratch_buf = nullptr;
     size_t scratch_cap = 0;
     unsigned long long* stamp_buf = nullptr;   // diagnostic: when set, conv3_rows runs its stamped variant
+    int chain_stamp_skip = -1;                        // diagnostic: >= 0 -> only the launch after that many fused launches is stamped (env SR355_CHAIN_STAMP_SKIP)
     unsigned long long* chain_stamp_buf = nullptr;   // diagnostic: when set, the fused dense-block kernels run their stamped variant
 
     // per-launch HIP-event timing of the hot kernels (sr_profile_begin/_end)

@@ -26,6 +26,7 @@
 // Epilogues: layer 0 = bias + ReLU -> bf16 -> LDS ring (+ global when a later kernel needs it); layer 1 = either the same
 // (growth conv) or the block's tail  alpha*(conv5 + b) + x [+ rrdb_in]  with x folded in from the staged chunk (the same
 // "skip from LDS" identity as conv_rows.hip) and written to channels [0,64) of the next block's buffer.
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -44,6 +45,7 @@ struct ChainParams {
     int B, H;
     int imgs_per_wg; unsigned magic;   // g / (H+1) == umulhi(g, magic) for every stream row index that occurs
     float alpha, xscale, beta_o;       // MODE 1: out = alpha * (acc + bias + xscale * x) + beta_o * so
+    int dbg_flags;                     // diagnostic builds only (env SR355_CHAIN_DBG_FLAGS): 1 = drop the tail's output stores, 2 = skip the external granules' MFMA bodies (timing experiments; results are wrong)
     unsigned long long* dbg;           // diagnostic builds only (sr_debug_set_chain_stamp_buffer): s_memtime stamps, [wg < 64][wave 0 / 5 / 8 / 11][granule < 64][4]
 };
 
@@ -60,25 +62,20 @@ template <int NB0, int NB1> struct ChainLds {
     static constexpr int BYTES = 2 * STGB + WINR * ROWB + NWS * WSLOT + (NB0 + NB1) * 16 * 4;
 };
 
-// lanes q and q^1 trade halves (v_permlane16_swap) so that every lane stores 8 consecutive channels (16 B): an even-q lane gets
-// channels 4q..4q+7 of block a, an odd-q lane channels 4(q-1)..4(q-1)+7 of block c  (same trick as conv_rows_epi.h)
-__device__ __forceinline__ void store_pair(const f32x4& a, const f32x4& c, char* dst) {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const bf16x4 ab = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
-    const bf16x4 cb = {(bf16_t)c[0], (bf16_t)c[1], (bf16_t)c[2], (bf16_t)c[3]};
-    const u32x2 au = __builtin_bit_cast(u32x2, ab), cu = __builtin_bit_cast(u32x2, cb);
-    const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
-    const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
-    const u32x4 o = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
-    *reinterpret_cast<u32x4*>(dst) = o;
-}
-
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // EXT: external 32-channel chunks both convs read; NB0 / NB1: 16-cout blocks of layer 0 / layer 1.
 // MODE 0: both layers are growth convs (ReLU) whose outputs go to chunks EXT and EXT+1 of the source buffer.
 // MODE 1: layer 0 is a growth conv kept on chip only, layer 1 is the block tail (NB1 = 4).
 #define CHAIN_STAMP(k) do { if (STAMP && blockIdx.x < 64 && G < 64 && (wave == 0 || wave == 5 || wave == 8 || wave == 11) && lane == 0)                \
         p.dbg[(((size_t)blockIdx.x * 4 + (wave == 0 ? 0 : wave == 5 ? 1 : wave == 8 ? 2 : 3)) * 64 + G) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + loader waves (LDS-DMA issue only), one loader per SIMD
 
@@ -195,46 +192,93 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
         };
         // Schedule.  In the iteration of granule g (after the barrier that opens g) a loader issues
         //   * the weights of granule g+2 into ring slot (g+2) % 3 (last read in granule g-1), and
-        //   * in the first two granules of an external chunk n, half of chunk n+1's 33 row pieces into staging buffer (n+1) & 1
-        //     (last read in chunk n-1),
+        //   * in each of the three granules of an external chunk n, a third of chunk n+1's 33 row pieces into staging buffer (n+1) & 1
+        //     (last read in chunk n-1) -- an even 29 pieces per iteration; 35 / 34 / 18 left the compute waves waiting ~1.4 k cycles for
+        //     the loaders in two granules of three and the loaders for the compute waves in the third,
         // then waits, with a COUNTED vmcnt, for what it issued in the PREVIOUS iteration (vmcnt retires in order) and meets the
         // barrier that opens granule g+1 -- which therefore publishes granule g+1's weights and, after the second granule of chunk n,
         // all of chunk n+1.  Every piece has a full granule of MFMA time to land; the loaders' own limit is the CU's vector-memory
         // issue port (~40-50 cycles per 1 KiB piece, in-kernel stamps).
-        // prologue: weights of granules 0 and 1, external chunk 0 of step 0; all of it is waited for before the first barrier
-        weights_of(0, 0, true, lw, NLOAD, 0, 1 << 20);
-        weights_of(1, 1, true, lw, NLOAD, 0, 1 << 20);
-        for (int k = lw; k < 33; k += NLOAD) stage_piece(0, 0, k, stg);
-        int nch = 0;
-        int s2w = 0, i2w = 1;                                            // position of granule G+1; advanced to G+2 before use
-        for (int s = 0; s < nsteps; ++s) {
-            for (int i = 0; i < NGR; ++i, ++G) {
-                CHAIN_STAMP(0);
-                // retire the previous iteration's pieces (all but the ones this iteration will issue are older) -- first iteration: everything
-                if (G == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                CHAIN_STAMP(1);
-                next_pos(s2w, i2w);                                      // -> granule G+2
-                int nissued = weights_of(G + 2, i2w, s2w < nsteps, lw, NLOAD, WCOMP, 1 << 20);   // the pieces the compute waves leave
-                if (i < EXTG) {
-                    const int c = i / 3, kx = i - 3 * c;
-                    if (kx < 2) {
-                        int c1 = c + 1, s2 = s;
-                        if (c1 == EXT) { c1 = 0; s2 = s + 1; }
-                        if (s2 < nsteps) {
-                            char* sdst = stg + ((nch + 1) & 1) * STGB;
-                            const int base = kx == 0 ? 0 : 17, cnt = kx == 0 ? 17 : 16;
-                            for (int k = lw; k < cnt; k += NLOAD, ++nissued) stage_piece(s2, c1, base + k, sdst);
-                        }
+        // Resident weights.  The path from L2 into a CU moves ~16 B/clk whatever issues the loads (stamps: loaders alone, compute
+        // bodies skipped, take the same ~65 cycles per 1 KiB piece; 8 or 252 workgroups on the chip make no difference), and
+        // every 8-row step re-reads ALL weights: 54 of a tail chunk's 87 pieces.  A loader wave needs ~30 registers and owns 168, so
+        // each keeps the first RT_E (RT_R) of its pieces of every external (ring) granule in registers for the whole kernel -- 132 KiB
+        // of the tail's 306 KiB, all of a growth pair's 90 / 126 KiB -- and writes them into the weight slot with ds_write_b128 (the
+        // LDS write path, not the memory port) where the DMA version issued a load.
+        constexpr int RT_E = MODE == 1 ? 2 : 3;                          // of ceil(3 NBT / 4) = 5 (tail) / 3 (growth pair) pieces per loader and granule
+        constexpr int RT_R = 2;                          // of ceil(3 NB1 / 4) = 3 / 2
+        u32x4 wre[EXTG][RT_E], wrr[3][RT_R];
+        auto wsrc_of = [&](int iw) { return p.w + (iw < EXTG ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024)); };
+#pragma unroll
+        for (int iw = 0; iw < EXTG; ++iw)
+#pragma unroll
+            for (int t = 0; t < RT_E; ++t)
+                if (lw + 4 * t < NBT * 3) wre[iw][t] = *reinterpret_cast<const u32x4*>(wsrc_of(iw) + (lw + 4 * t) * 1024 + lane * 16);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int t = 0; t < RT_R; ++t)
+                if (lw + 4 * t < NB1 * 3) wrr[r][t] = *reinterpret_cast<const u32x4*>(wsrc_of(EXTG + r) + (lw + 4 * t) * 1024 + lane * 16);
+        // weights of the granule at position IW of a step (running number Gw) -> slot Gw % NWS; returns the DMA pieces issued
+        auto put_weights = [&](auto IW, int Gw, bool live) -> int {
+            constexpr int iw = decltype(IW)::value;
+            constexpr bool ext = iw < EXTG;
+            constexpr int nw = ext ? NBT * 3 : NB1 * 3, rt = ext ? RT_E : RT_R;
+            if (!live) return 0;
+            const char* wq = p.w;
+            asm volatile("" : "+s"(wq));                                 // recompute the piece addresses here: hoisted out of the step loop they cost two registers each
+            const char* wsrc = wq + (ext ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024));
+            char* wdst = wr + (Gw % NWS) * WSLOT;
+            int n = 0;
+#pragma unroll
+            for (int t = 0; t < (nw + 3) / 4; ++t) {
+                const int k = lw + 4 * t;
+                if (k < nw) {
+                    if (t < rt) {
+                        if constexpr (ext) *reinterpret_cast<u32x4*>(wdst + k * 1024 + lane * 16) = wre[ext ? iw : 0][t < RT_E ? t : 0];
+                        else *reinterpret_cast<u32x4*>(wdst + k * 1024 + lane * 16) = wrr[ext ? 0 : iw - EXTG][t < RT_R ? t : 0];
                     } else {
-                        ++nch;
+                        dma(wsrc + k * 1024 + lane * 16, wdst + k * 1024);
+                        ++n;
                     }
                 }
-                CHAIN_STAMP(2);
-                // wait for the PREVIOUS iteration's pieces: all but this iteration's `nissued` youngest (vmcnt retires in order)
-                wait_all_but(nissued);
-                CHAIN_STAMP(3);
             }
+            return n;
+        };
+        // prologue: weights of granules 0 and 1, external chunk 0 of step 0; all of it is waited for before the first barrier
+        put_weights(std::integral_constant<int, 0>{}, 0, true);
+        put_weights(std::integral_constant<int, 1>{}, 1, true);
+        for (int k = lw; k < 33; k += NLOAD) stage_piece(0, 0, k, stg);
+        int nch = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            static_for<NGR>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                CHAIN_STAMP(0);
+                // retire the previous iteration's pieces (all but the ones this iteration will issue are older) -- first iteration: everything
+                if (G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the resident pieces written in the previous iteration
+                __builtin_amdgcn_s_barrier();
+                CHAIN_STAMP(1);
+                constexpr int i2 = (i + 2) % NGR;                        // granule G+2
+                int nissued = put_weights(std::integral_constant<int, i2>{}, G + 2, i + 2 < NGR || s + 1 < nsteps);
+                bool publish_now = false;
+                if constexpr (i < EXTG) {
+                    constexpr int c = i / 3, kx = i - 3 * c;
+                    int c1 = c + 1, s2 = s;
+                    if (c1 == EXT) { c1 = 0; s2 = s + 1; }
+                    if (s2 < nsteps) {
+                        char* sdst = stg + ((nch + 1) & 1) * STGB;
+                        for (int k = 11 * kx + lw; k < 11 * kx + 11; k += NLOAD, ++nissued) stage_piece(s2, c1, k, sdst);
+                    }
+                    if (kx == 2) { ++nch; publish_now = true; }
+                }
+                CHAIN_STAMP(2);
+                // wait for the PREVIOUS iteration's pieces: all but this iteration's `nissued` youngest (vmcnt retires in order); the last third
+                // of a chunk's rows is read right after the next barrier, so that iteration waits for its own pieces too
+                wait_all_but(publish_now ? 0 : nissued);
+                CHAIN_STAMP(3);
+                ++G;
+            });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -255,6 +299,17 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
 
     f32x4 a0[NB0][3], a1[NB1][3];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // Output rows leave through LDS.  In the MFMA result layout lane (px, q) holds 8 channels of pixel px, so neighbouring lanes are 64 B
+    // apart and a 16-byte global store per lane reaches memory as 64 separate 16-byte writes: ~600 cycles per store instruction and wave
+    // (stamps, the same with 8 workgroups on the chip as with 252), ~8 k cycles per step for the tail's 48.  Each 1 KiB piece (16 pixels x
+    // 64 B) is therefore written to a private LDS slot in its memory order (slices XOR-swizzled by (px >> 1) & 3: conflict free) and read
+    // back 16 B per lane in lane order, which stores -- and, for the RRDB skip, loads -- whole cache lines.  The slots live in the staging
+    // buffer of the external chunk just finished, which nobody touches between the barrier after the last external granule and the one
+    // that opens the next step (4 KiB per wave).
+    const int t_a = px * 64 + 16 * ((q >> 1) ^ ((px >> 1) & 3)) + (q & 1) * 8;     // slot offset of channels [4q, 4q+4) of pixel px; channels [16+4q, ..) are at t_a ^ 32
+    const int t_line = (lane >> 2) * 64 + 16 * ((lane & 3) ^ ((lane >> 3) & 3));   // slot offset of the piece's bytes [16 l, 16 l + 16) for lane l
+    const bool early = wave < NCOMP / 2;
 
     // Row-major walk of a granule: the three column-group fragments of one input row are read once and meet every weight fragment that
     // row pairs with (both layers, one ky each) before the next row is touched -- 12 + 6 x 4 registers of operands live at a time.
@@ -358,7 +413,8 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 CHAIN_STAMP(1);
                 CHAIN_STAMP(2);
                 const char* ws = wr + (G % NWS) * WSLOT;
-                if (kx == 0) ext_granule(std::integral_constant<int, 0>{}, sb, ws);
+                if (STAMP && (p.dbg_flags & 2)) { /* timing experiment: loaders alone */ }
+                else if (kx == 0) ext_granule(std::integral_constant<int, 0>{}, sb, ws);
                 else if (kx == 1) ext_granule(std::integral_constant<int, 1>{}, sb, ws);
                 else ext_granule(std::integral_constant<int, 2>{}, sb, ws);
                 CHAIN_STAMP(3);
@@ -402,71 +458,91 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                     const int slice = n * 2 + (q >> 1);
                     *reinterpret_cast<bf16x4*>(wrow + cg * 1024 + 64 * px + 16 * (slice ^ (2 * ((px >> 2) & 1))) + (q & 1) * 8) = o;
                 }
-                if (MODE == 0 && grow) {
-                    static_assert(MODE == 1 || NB0 == 2, "growth convs have 32 output channels");
-                    store_pair(v[0], v[NB0 - 1], grow + (16 * cg + px) * 64 + ((q & 1) * 16 + 4 * (q & ~1)) * 2);
+            }
+            if (MODE == 0 && grow) {
+                // the ring row just written IS the row's memory image (64 B per pixel, slices swizzled by 2 * bit2(pixel)): read it back in
+                // lane order and store whole lines
+                static_assert(MODE == 1 || NB0 == 2, "growth convs have 32 output channels");
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int cg = 0; cg < 3; ++cg) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(wrow + cg * 1024 + (lane >> 2) * 64 + 16 * ((lane & 3) ^ (2 * ((lane >> 4) & 1))));
+                    *reinterpret_cast<u32x4*>(grow + cg * 1024 + lane * 16) = v;
                 }
             }
         }
+        char* const tb = stg + ((nch + 1) & 1) * STGB + wave * 4096;       // transposition slots (free staging buffer, see above)
+        // the other skip tensor of an RRDB's last block (beta_o * so) is folded into layer 1's accumulators as (beta_o / alpha) * so while
+        // layer 1 runs on the ring: column group kx's two 16-byte loads are issued around the barrier of ring granule kx (early waves
+        // behind it, late waves in front of it) and consumed after that granule's MFMAs -- eight registers for one granule
+        u32x4 sl[2];
+        const char* sob = nullptr;
+        if (MODE == 1 && HAS_O) {
+            int img, y;
+            if (row_of(8 * s + wave - 1, img, y)) sob = p.so + ((int64_t)(img0 + img) * H + y) * p.so_nch * ROWB;
+        }
+        auto so_fetch = [&](int cg) {
+            if (MODE == 1 && HAS_O && sob) {
+                sl[0] = *reinterpret_cast<const u32x4*>(sob + cg * 1024 + lane * 16);
+                sl[1] = *reinterpret_cast<const u32x4*>(sob + ROWB + cg * 1024 + lane * 16);
+            }
+        };
         // ---- layer 1 on layer 0's output
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx, ++G) {
             CHAIN_STAMP(0);
+            if (!early) so_fetch(kx);
             sync();
             CHAIN_STAMP(1);
+            if (early) so_fetch(kx);
             CHAIN_STAMP(2);
             const char* ws = wr + (G % NWS) * WSLOT;
             if (kx == 0) ring_granule(std::integral_constant<int, 0>{}, s, ws);
             else if (kx == 1) ring_granule(std::integral_constant<int, 1>{}, s, ws);
             else ring_granule(std::integral_constant<int, 2>{}, s, ws);
+            if (MODE == 1 && HAS_O && sob) {
+                const float sc2 = p.beta_o / p.alpha;
+#pragma unroll
+                for (int h = 0; h < NB1 / 2; ++h) {
+                    *reinterpret_cast<u32x4*>(tb + h * 1024 + t_line) = sl[h];
+                    asm volatile("" ::: "memory");
+                    const bf16x4 ka = *reinterpret_cast<const bf16x4*>(tb + h * 1024 + t_a);
+                    const bf16x4 kc = *reinterpret_cast<const bf16x4*>(tb + h * 1024 + (t_a ^ 32));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a1[2 * h][kx][e] += sc2 * (float)ka[e];
+                        a1[2 * h + 1][kx][e] += sc2 * (float)kc[e];
+                    }
+                }
+            }
             CHAIN_STAMP(3);
         }
-        // ---- layer 1 epilogue (row 8s+w-1)
+        // ---- layer 1 epilogue (row 8s+w-1): bias (+ ReLU | * alpha) -> bf16 -> transposition slot -> whole-line stores
         {
             int img, y;
             const bool real = row_of(8 * s + wave - 1, img, y);
-            if (real) {
+            if (real && !(STAMP && (p.dbg_flags & 1))) {
                 const int64_t rowi = (int64_t)(img0 + img) * H + y;
-                const int lane_c = (q & 1) * 16 + 4 * (q & ~1);
-                if (MODE == 0) {
-                    char* grow = const_cast<char*>(p.in) + (rowi * p.in_nch + EXT + 1) * ROWB;
+                char* const grow = MODE == 0 ? const_cast<char*>(p.in) + (rowi * p.in_nch + EXT + 1) * ROWB : p.out + rowi * p.out_nch * ROWB;
+                const float alpha = p.alpha;
 #pragma unroll
-                    for (int cg = 0; cg < 3; ++cg) {
-                        f32x4 v[2];
+                for (int cg = 0; cg < 3; ++cg)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) {
+                    for (int h = 0; h < NB1 / 2; ++h) {
+                        char* const slot = tb + ((2 * cg + h) & 3) * 1024;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int n = 2 * h + u;
                             const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + (NB0 + n) * 16 + 4 * q);
+                            f32x4 v;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[n][e] = fmaxf(a1[n][cg][e] + b[e], 0.f);
+                            for (int e = 0; e < 4; ++e) v[e] = MODE == 0 ? fmaxf(a1[n][cg][e] + b[e], 0.f) : alpha * (a1[n][cg][e] + b[e]);
+                            *reinterpret_cast<bf16x4*>(slot + (t_a ^ (32 * u))) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         }
-                        store_pair(v[0], v[1], grow + (16 * cg + px) * 64 + lane_c * 2);
+                        asm volatile("" ::: "memory");                 // the read-back below is of other lanes' writes: keep the order
+                        const u32x4 line = *reinterpret_cast<const u32x4*>(slot + t_line);
+                        *reinterpret_cast<u32x4*>(grow + h * ROWB + cg * 1024 + lane * 16) = line;
                     }
-                } else {
-                    const float alpha = p.alpha, beta_o = p.beta_o;
-#pragma unroll
-                    for (int cg = 0; cg < 3; ++cg) {
-                        bf16x4 ko[NB1];
-                        if (HAS_O) {
-                            const char* srow = p.so + rowi * p.so_nch * ROWB;
-#pragma unroll
-                            for (int n = 0; n < NB1; ++n)
-                                ko[n] = *reinterpret_cast<const bf16x4*>(srow + (n >> 1) * ROWB + (16 * cg + px) * 64 + ((n & 1) * 16 + 4 * q) * 2);
-                        }
-                        f32x4 v[NB1];
-#pragma unroll
-                        for (int n = 0; n < NB1; ++n) {
-                            const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + (NB0 + n) * 16 + 4 * q);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[n][e] = alpha * (a1[n][cg][e] + b[e]);
-                                if (HAS_O) v[n][e] += beta_o * (float)ko[n][e];
-                            }
-                        }
-#pragma unroll
-                        for (int h = 0; h < NB1 / 2; ++h)
-                            store_pair(v[2 * h], v[2 * h + 1], p.out + (rowi * p.out_nch + h) * ROWB + (16 * cg + px) * 64 + lane_c * 2);
-                    }
-                }
             }
         }
     }
@@ -588,6 +664,9 @@ int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H
     if ((int64_t)p.imgs_per_wg * (H + 1) + 16 >= (1ll << 20)) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: stream too long");
     p.alpha = alpha; p.xscale = tail ? beta_x / alpha : 0.f; p.beta_o = beta_o;
     p.dbg = ctx->chain_stamp_buf;
+    { const char* f = getenv("SR355_CHAIN_DBG_FLAGS"); p.dbg_flags = f ? atoi(f) : 0; }
+    if (p.dbg && ctx->chain_stamp_skip >= 0 && ctx->chain_stamp_skip-- != 0) p.dbg = nullptr;   // stamp one chosen launch only
+    if (p.dbg && ctx->chain_stamp_skip == -1 && getenv("SR355_CHAIN_STAMP_SKIP")) ctx->chain_stamp_buf = nullptr;
     int rec = -1;
     if (ctx->prof) {
         const double px = (double)B * H * W;
