@@ -249,7 +249,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
         put_weights(std::integral_constant<int, 0>{}, 0, true);
         put_weights(std::integral_constant<int, 1>{}, 1, true);
         for (int k = lw; k < 33; k += NLOAD) stage_piece(0, 0, k, stg);
-        int nch = 0;
+        int nch = 0, prev_stage = 0;
         for (int s = 0; s < nsteps; ++s) {
             static_for<NGR>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -260,22 +260,28 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 __builtin_amdgcn_s_barrier();
                 CHAIN_STAMP(1);
                 constexpr int i2 = (i + 2) % NGR;                        // granule G+2
-                int nissued = put_weights(std::integral_constant<int, i2>{}, G + 2, i + 2 < NGR || s + 1 < nsteps);
-                bool publish_now = false;
+                const bool wlive = i + 2 < NGR || s + 1 < nsteps;
+                constexpr int kxi = i < EXTG ? i % 3 : -1;
+                // vmcnt retires in order, so the order of issue decides what the counted wait can leave in flight.  What the next barrier
+                // must publish: the weights of granule G+1 (issued FIRST in the previous iteration) and, after the third granule of a chunk,
+                // all of the next chunk's rows.  Granules 0 / 1 of a chunk: weights, then rows; wait for all but (the previous iteration's
+                // rows + everything of this one).  Granule 2: rows first, then weights; wait for all but these weights.
+                int nw_dma = 0, nst = 0;
+                if (kxi != 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + 2, wlive);
                 if constexpr (i < EXTG) {
                     constexpr int c = i / 3, kx = i - 3 * c;
                     int c1 = c + 1, s2 = s;
                     if (c1 == EXT) { c1 = 0; s2 = s + 1; }
                     if (s2 < nsteps) {
                         char* sdst = stg + ((nch + 1) & 1) * STGB;
-                        for (int k = 11 * kx + lw; k < 11 * kx + 11; k += NLOAD, ++nissued) stage_piece(s2, c1, k, sdst);
+                        for (int k = 11 * kx + lw; k < 11 * kx + 11; k += NLOAD, ++nst) stage_piece(s2, c1, k, sdst);
                     }
-                    if (kx == 2) { ++nch; publish_now = true; }
+                    if (kx == 2) ++nch;
                 }
+                if (kxi == 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + 2, wlive);
                 CHAIN_STAMP(2);
-                // wait for the PREVIOUS iteration's pieces: all but this iteration's `nissued` youngest (vmcnt retires in order); the last third
-                // of a chunk's rows is read right after the next barrier, so that iteration waits for its own pieces too
-                wait_all_but(publish_now ? 0 : nissued);
+                wait_all_but(kxi == 2 ? nw_dma : nw_dma + nst + prev_stage);
+                prev_stage = kxi == 2 ? 0 : nst;
                 CHAIN_STAMP(3);
                 ++G;
             });

@@ -22,6 +22,16 @@ def test_conv_rows_assembly_has_no_prefetch_hazard_and_no_spill():
     assert " 0 problems" in r.stdout
 
 
+def test_fused_dense_kernels_use_no_scratch():
+    """csrc/dense_fused.hip: the loader waves' counted vmcnt waits and the 168-register budget of three waves per SIMD both need a
+    spill-free build of every chain2_kernel instance."""
+    src = os.path.join(ROOT, "super-resolution-images-for-3d-printing-defect-detection_amd", "csrc", "dense_fused.hip")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch_hazards.py"), "--source", src, "--match", "chain2_kernel",
+                        "--scratch-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "9 kernels checked" in r.stdout and " 0 problems" in r.stdout
+
+
 def test_checker_flags_a_register_touched_under_an_outstanding_load():
     C = _checker()
     bad = """
