@@ -134,3 +134,43 @@ def test_forward_errors(ctx):
         m.set_weights({})
     with pytest.raises(ValueError):
         Model("edsr", scale_factor=5, ctx=ctx)
+
+
+def test_cfg1_full_size_srcnn_fp32(ctx):
+    """BASELINE configs[1] at its full size: LR [32,256,256,3] fp32 -> bicubic x4 -> SRCNN -> [32,1024,1024,3] (33.55 MPix).  The oracle
+    cannot run 1.9 TFLOP, so: the bicubic of two whole images against the oracle's cv2.resize restatement; the network on 76x76
+    windows of the device's own up-scaled batch (receptive field radius 4 + 0 + 2 = 6: the window's 64x64 core is exact), at a
+    corner, an edge and in the interior -- which also pins the SAME zero padding at full size; PSNR / SSIM of two output images; and
+    the batch is independent image by image (image 7 alone gives the same bytes as image 7 of the batch)."""
+    rng = np.random.default_rng(43)
+    lr = rng.uniform(0, 1, (32, 256, 256, 3)).astype(np.float32)
+    m = Model("srcnn", compute_dtype="f32", ctx=ctx)
+    w = init_weights(m.layer_shapes(), seed=1000)
+    m.set_weights(w)
+    x = ctx.to_device(lr)
+    up = ctx.bicubic(x, 1024, 1024)
+    assert up.shape == (32, 1024, 1024, 3)
+    for b in (0, 31):
+        ref = O.cv_resize(lr[b], 1024, 1024, O.INTER_CUBIC)
+        assert np.max(np.abs(up[b].cpu().numpy() - ref)) <= 2e-6
+    y = m.forward(up)
+    assert y.shape == (32, 1024, 1024, 3) and bool(torch.isfinite(y).all())
+    uph = up.cpu().numpy()
+    for b, y0, x0 in [(0, 0, 0), (5, 0, 500), (17, 960, 960), (31, 400, 0), (12, 300, 700)]:
+        ys, xs = max(y0 - 6, 0), max(x0 - 6, 0)
+        ye, xe = min(y0 + 70, 1024), min(x0 + 70, 1024)
+        win = uph[b:b + 1, ys:ye, xs:xe]
+        # the oracle pads the window with zeros at its borders: identical to the network only where the window border IS the image border
+        ref = M.srcnn_forward(win, w, dtype=np.float64)[0]
+        cy0, cx0 = y0 - ys, x0 - xs
+        core_ref = ref[cy0:cy0 + 64, cx0:cx0 + 64]
+        core_got = y[b, y0:y0 + 64, x0:x0 + 64].cpu().numpy()
+        assert core_ref.shape == (64, 64, 3) and rel_l2(core_got, core_ref) <= 1e-5, (b, y0, x0, rel_l2(core_got, core_ref))
+    hr = ctx.to_device(np.clip(uph[[3, 30]] + 0.02 * rng.standard_normal((2, 1024, 1024, 3)), 0, 1).astype(np.float32))
+    sel = y[[3, 30]].contiguous()
+    p, s = ctx.psnr(hr, sel).cpu().numpy(), ctx.ssim(hr, sel).cpu().numpy()
+    pr = O.psnr(hr.cpu().numpy(), sel.cpu().numpy(), dtype=np.float64)
+    sr = O.ssim(hr.cpu().numpy(), sel.cpu().numpy(), dtype=np.float64)
+    assert np.max(np.abs(p - pr)) <= 1e-3 and np.max(np.abs(s - sr)) <= 1e-4
+    alone = m.forward(up[7:8].contiguous())
+    assert torch.equal(alone[0], y[7])
