@@ -182,6 +182,14 @@ int  sr_spectral_l1(sr_ctx* ctx, const void* a, const void* b, int B, int H, int
  * sr_space_to_depth: the inverse of tf.nn.depth_to_space (DCR order): x [B,H*r,W*r,C] -> y [B,H,W,r*r*C] (its gradient). */
 int  sr_conv2d_wgrad(sr_ctx* ctx, const void* x, const void* dy, int B, int H, int W, int Cin, int Cout, int K,
                      float* dw_hwio, float* db, void* stream);
+/* sr_conv2d with DEVICE fp32 weights (the training loop keeps its parameters on the device between optimiser steps): d_w is a device
+ * HWIO tensor [K,K,Cin,Cout]; with rot = 1 it is instead the forward kernel [K,K,Cout,Cin] of the layer whose INPUT gradient is wanted,
+ * and the conv runs on its 180-degree-rotated, channel-swapped form (ESRGAN_model.py:505-533 via tf.GradientTape).  The kernel is packed
+ * into MFMA fragment order by a device kernel; fully asynchronous on `stream`; scratch is reused call to call in stream order, so one
+ * stream per context.  fp32 tensors only. */
+int  sr_conv2d_dev(sr_ctx* ctx, const void* x, int B, int H, int W, int Cin, const float* d_w, const float* d_bias, int K, int Cout,
+                   int rot, int act, float alpha, const void* skip1, float beta1, const void* skip2, float beta2, int clip01,
+                   int d2s_r, void* y, void* stream);
 int  sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, float beta, void* out, int64_t n, void* stream);
 int  sr_space_to_depth(sr_ctx* ctx, const void* x, int B, int H, int W, int C, int r, void* y, void* stream);
 /* More halves of ESRGAN._train_step's backward pass (ESRGAN_model.py:475-533), fp32 device tensors:

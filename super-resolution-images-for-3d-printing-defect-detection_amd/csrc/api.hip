@@ -60,6 +60,15 @@ void* sr_ctx::scratch(size_t bytes) {
     return scratch_buf;
 }
 
+void* sr_ctx::arena(Arena& a, size_t bytes, hipStream_t st) {
+    if (bytes <= a.cap) return a.p;
+    if (a.p) { (void)hipStreamSynchronize(st); dfree(a.p); a.p = nullptr; a.cap = 0; }
+    const size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
+    a.p = dalloc(cap);
+    if (a.p) a.cap = cap;
+    return a.p;
+}
+
 int sr_ctx::prof_open(const std::string& name, double flops, double bytes, hipStream_t st) {
     if (!prof) return -1;
     int ni = -1;
@@ -876,6 +885,30 @@ int sr_conv2d(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int Ci
     conv_free_weights(ctx, &cw);
     if (!rc && e != hipSuccess) return ctx->fail(SR_ERR_HIP, std::string("conv2d: ") + hipGetErrorString(e));
     return rc;
+}
+
+int sr_conv2d_dev(sr_ctx* ctx, const void* x, int B, int H, int W, int Cin, const float* d_w, const float* d_bias, int K, int Cout, int rot,
+                  int act, float alpha, const void* skip1, float beta1, const void* skip2, float beta2, int clip01, int d2s_r, void* y,
+                  void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!x || !d_w || !y) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ctx->fail(SR_ERR_INVALID, "bad tensor shape");
+    ConvWeights cw;
+    int rc = conv_pack_weights_dev(ctx, d_w, d_bias, K, Cin, Cout, rot, &cw, st);
+    if (rc) return rc;
+    const int Cp = cw.thin ? cw.CinP : round_up(cw.CinP, 32);
+    void* xp = ctx->arena(ctx->dev_x, (size_t)B * H * W * Cp * 4 + 4096, st);
+    if (!xp) return SR_ERR_OOM;
+    rc = convert_pad_launch(ctx, x, SR_DTYPE_F32, (int64_t)B * H * W, Cin, xp, SR_DTYPE_F32, Cp, 1.f, 0.f, st);
+    if (rc) return rc;
+    ConvEpilogue ep;
+    ep.act = act; ep.alpha = alpha; ep.clip01 = clip01; ep.d2s_r = d2s_r < 1 ? 1 : d2s_r;
+    if (skip1) { ep.skip1 = {skip1, Cout, 0}; ep.beta1 = beta1; }
+    if (skip2) { ep.skip2 = {skip2, Cout, 0}; ep.beta2 = beta2; }
+    const int r = ep.d2s_r;
+    return conv_launch(ctx, cw, TensorView{xp, Cp, 0}, B, H, W, y, Cout / (r * r), 0, ep, st);
 }
 
 int sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, const float* wf, const float* bf, const float* wg,

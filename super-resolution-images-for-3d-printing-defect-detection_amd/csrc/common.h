@@ -46,6 +46,9 @@ struct sr_ctx {
     std::unordered_set<const void*> lds_attr_done;
     int ensure_dyn_lds(const void* kernel, int bytes);
     void* tab_buf = nullptr; size_t tab_cap = 0;   // tap tables of sr_resize (stream-ordered reuse)
+    struct Arena { void* p = nullptr; size_t cap = 0; };
+    Arena dev_w, dev_b, dev_x;    // sr_conv2d_dev: packed weights / padded bias / padded input of the call in flight (stream-ordered reuse)
+    void* arena(Arena& a, size_t bytes, hipStream_t st);   // grow-only; growing waits for `st` first
     void* zero_page = nullptr;    // 4 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int chain_mask = 3;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3 (sr_debug_set_fused; default both)
@@ -117,6 +120,10 @@ struct ConvEpilogue {
 };
 
 // host: pack HWIO fp32 weights (+bias) for the device.  Returns SR_OK or error (ctx->err set).
+// the same packing on the device (fp32 only): `d_hwio` is a device HWIO tensor, [K,K,Cin,Cout], or with rot = 1 the kernel whose
+// 180-degree-rotated, channel-swapped form is wanted ([K,K,Cout,Cin]: the input-gradient conv of that layer); weights and bias land in
+// the context's arenas (valid until the next sr_conv2d_dev on the stream)
+int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias, int KS, int Cin, int Cout, int rot, ConvWeights* out, hipStream_t st);
 int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS, int Cin, int Cout,
                       int dtype, ConvWeights* out);
 void conv_free_weights(sr_ctx* ctx, ConvWeights* w);

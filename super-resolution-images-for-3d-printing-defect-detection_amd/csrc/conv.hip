@@ -480,6 +480,91 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
     return SR_OK;
 }
 
+// ---- device-side packing (fp32): one thread per packed element decodes its (tap, cin, cout) exactly as the host loops above
+__global__ void pack_weights_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int layout, int ntap, int Cin, int Cout,
+                                        int CinP, int NT, int nchunks, int KGPT, int rot) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        int tap, ci, co;
+        if (layout == 0) {                        // few: [tap][CinP][4]
+            co = (int)(idx & 3);
+            const int64_t t = idx >> 2;
+            ci = (int)(t % CinP); tap = (int)(t / CinP);
+        } else if (layout == 1) {                 // thin: [ct][g][n][lane][j], E = 4
+            const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+            int64_t t = idx >> 8;
+            const int nn = (int)(t % NT); t /= NT;
+            const int g = (int)(t % nchunks), ct = (int)(t / nchunks);          // nchunks = KGT
+            tap = 2 * g + (lane >> 5); ci = j; co = (ct * NT + nn) * 32 + (lane & 31);
+        } else {                                  // wide: [ct][ch][tap][kg][n][lane][j], E = 4
+            const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+            int64_t t = idx >> 8;
+            const int nn = (int)(t % NT); t /= NT;
+            const int kg = (int)(t % KGPT); t /= KGPT;
+            tap = (int)(t % ntap); t /= ntap;
+            const int ch = (int)(t % nchunks), ct = (int)(t / nchunks);
+            ci = ch * (KGPT * 8) + kg * 8 + (lane >> 5) * 4 + j; co = (ct * NT + nn) * 32 + (lane & 31);
+        }
+        float v = 0.f;
+        if (tap < ntap && ci < Cin && co < Cout)
+            v = rot ? src[((int64_t)(ntap - 1 - tap) * Cout + co) * Cin + ci] : src[((int64_t)tap * Cin + ci) * Cout + co];
+        dst[idx] = v;
+    }
+}
+
+__global__ void pad_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int Cout, int CoutP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < CoutP) out[i] = (b && i < Cout) ? b[i] : 0.f;
+}
+
+int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias, int KS, int Cin, int Cout, int rot, ConvWeights* out, hipStream_t st) {
+    if (KS != 1 && KS != 3 && KS != 5 && KS != 9) return ctx->fail(SR_ERR_INVALID, "conv: kernel size must be 1,3,5 or 9");
+    const int E = 4, ntap = KS * KS;
+    ConvWeights w;                                // the metadata of conv_pack_weights for dtype f32
+    w.dtype = SR_DTYPE_F32; w.KS = KS; w.Cin = Cin; w.Cout = Cout;
+    w.CoutP = round_up(Cout, 32);
+    const int nb = w.CoutP / 32;
+    w.NT = (nb % 2 == 0) ? 2 : (nb % 3 == 0 ? 3 : 1);
+    if (KS == 5 && !(Cin <= E)) w.NT = 1;
+    if (Cin <= E) w.NT = 1;
+    const int nct = nb / w.NT;
+    w.thin = Cin <= E;
+    w.few = (Cout <= 4 && !w.thin && (KS == 3 || KS == 5)) ? 1 : 0;
+    w.rows = 0; w.pw = 0;
+    if (!w.thin && KS == 9) return ctx->fail(SR_ERR_INVALID, "conv: 9x9 supported for <= one 16-byte channel slice only");
+    int layout;
+    int64_t n;
+    if (w.few) {
+        layout = 0;
+        w.CoutP = 4; w.NT = 1; w.KGPT = 0;
+        w.CinP = round_up(Cin, 4);
+        w.nchunks = w.CinP / 4;
+        n = (int64_t)ntap * w.CinP * 4;
+    } else if (w.thin) {
+        layout = 1;
+        w.CinP = E; w.KGPT = 0;
+        w.nchunks = (ntap + 1) / 2;
+        n = (int64_t)nct * w.nchunks * w.NT * 256;
+    } else {
+        layout = 2;
+        w.KGPT = (KS == 1 && (round_up(Cin, 4 * E) * 4) % 128 == 0) ? 4 : 2;
+        const int chunkE = w.KGPT * 2 * E;
+        w.CinP = round_up(Cin, chunkE);
+        w.nchunks = w.CinP / chunkE;
+        n = (int64_t)nct * w.nchunks * ntap * w.KGPT * w.NT * 256;
+    }
+    w.bytes = (size_t)n * 4;
+    w.w = ctx->arena(ctx->dev_w, w.bytes, st);
+    w.bias = static_cast<float*>(ctx->arena(ctx->dev_b, sizeof(float) * round_up(w.CoutP, 64), st));
+    if (!w.w || !w.bias) return SR_ERR_OOM;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weights_f32_kernel, dim3(blocks), dim3(256), 0, st, d_hwio, static_cast<float*>(w.w), n, layout, ntap, Cin, Cout, w.CinP,
+                       w.NT, w.nchunks, w.KGPT, rot);
+    hipLaunchKernelGGL(pad_bias_kernel, dim3((w.CoutP + 63) / 64), dim3(64), 0, st, d_bias, w.bias, Cout, w.CoutP);
+    SR_HIP(ctx, hipGetLastError());
+    *out = w;
+    return SR_OK;
+}
+
 void conv_free_weights(sr_ctx* ctx, ConvWeights* w) {
     if (w->w) ctx->dfree(w->w);
     if (w->bias) ctx->dfree(w->bias);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "sr_psnr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sr_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "sr_conv2d_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _vp, _f, _i, _i, _vp, _vp]),
     "sr_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sr_eltwise": (_i, [_vp, _i, _vp, _vp, _f, _f, _vp, _i64, _vp]),
     "sr_space_to_depth": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

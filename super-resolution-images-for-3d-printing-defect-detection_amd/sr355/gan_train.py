@@ -12,7 +12,8 @@ The forward and backward passes are host orchestration over the C ABI's single o
   * a minimal reverse-mode tape (below) keeps the graph bookkeeping out of the kernels; torch is used for memory only (cat / slice /
     flip / expand: data movement).
 Tiny vectors -- the discriminator's [B,256] dense head, BCE on [B,1], spectral-norm power iteration, Adam -- run on the host in NumPy.
-This path is functional, not fast (every layer call re-packs its weights); cfg3's throughput is not a bench line yet.
+Parameters are uploaded once per step and packed into MFMA fragment order on the device per layer call (sr_conv2d_dev); the
+optimisers and the tape bookkeeping stay on the host.  cfg3's throughput is recorded by tools/bench_train.py, not yet a bench line.
 """
 import numpy as np
 import torch
@@ -33,9 +34,17 @@ class Tape:
     """Reverse-mode bookkeeping: ops push a closure; backward() runs them last-to-first.  Parameter gradients land in `grads`
     ({layer: [dk, db]}, summed over uses) when `wgrad` is on."""
 
-    def __init__(self, ctx, weights, wgrad=True):
+    def __init__(self, ctx, weights, wgrad=True, devcache=None):
         self.ctx, self.w, self.wgrad = ctx, weights, wgrad
         self.ops, self.grads = [], {}
+        self.dev = devcache if devcache is not None else {}     # id(host array) -> (host array, device tensor): one upload per array
+
+    def _dev(self, a):
+        hit = self.dev.get(id(a))
+        if hit is None or hit[0] is not a:
+            hit = (a, self.ctx.to_device(np.ascontiguousarray(a, np.float32)))
+            self.dev[id(a)] = hit
+        return hit[1]
 
     def _acc(self, var, g):
         if not var.need:
@@ -54,7 +63,8 @@ class Tape:
         """Keras Conv2D SAME stride 1 (+ activation, + depth_to_space for the upsample blocks)."""
         ctx = self.ctx
         k, b = kernel if kernel is not None else self.w[name]
-        y = Var(ctx.conv2d(x.v, k, b, act=act, d2s=d2s))
+        kd = self._dev(k)
+        y = Var(ctx.conv2d_dev(x.v, kd, self._dev(b), k.shape[3], act=act, d2s=d2s))
 
         def bwd():
             if y.g is None:
@@ -72,7 +82,7 @@ class Tape:
                 dw, db = ctx.conv2d_wgrad(x.v, dz, k.shape[0])
                 self._pgrad(name, dw, db)
             if x.need:
-                self._acc(x, ctx.conv2d(dz, _rot(k), None))
+                self._acc(x, ctx.conv2d_dev(dz, kd, None, k.shape[2], rot=True))
         self.ops.append(bwd)
         return y
 
@@ -291,16 +301,19 @@ class ESRGANTrainer:
         """-> {'g_loss', 'd_loss', parts...}; weights, u, optimiser states advance in place (ESRGAN_model.py:475-533)."""
         ctx = self.ctx
         lr_t, hr_t = ctx.to_device(np.asarray(lr_images, np.float32)), ctx.to_device(np.asarray(hr_images, np.float32))
+        devc = {}                                          # device copies of this step's parameter arrays (one upload per array)
+        if not hasattr(self, "_vggc"):
+            self._vggc = {}                                # the frozen VGG19 stays on the device
         # ---- discriminator update
-        tg = Tape(ctx, self.gw, wgrad=False)
+        tg = Tape(ctx, self.gw, wgrad=False, devcache=devc)
         fake = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att).v
-        td = Tape(ctx, self.dw)
+        td = Tape(ctx, self.dw, devcache=devc)
         p_real, seed_real = discriminator_forward(td, Var(hr_t, need=False), True, self.u)       # renormalisation 1
         l_real, dp = bce_mean(np.ones_like(p_real), p_real)
         seed_real(dp)
         td.backward()
         g_real = self._host(td.grads)
-        td2 = Tape(ctx, self.dw)
+        td2 = Tape(ctx, self.dw, devcache=devc)
         p_fake, seed_fake = discriminator_forward(td2, Var(fake, need=False), True, self.u)      # renormalisation 2
         l_fake, dp = bce_mean(np.zeros_like(p_fake), p_fake)
         seed_fake(dp)
@@ -312,17 +325,17 @@ class ESRGANTrainer:
         self.d_opt.lr = staircase_lr(self.d_lr0, self.step)
         self.dw = self.d_opt.apply(self.dw, d_grads)
         # ---- generator update
-        tg = Tape(ctx, self.gw)
+        tg = Tape(ctx, self.gw, devcache=devc)
         x = Var(lr_t, need=False)
         y = generator_forward(tg, x, self.scale, self.nb, self.att)
-        td3 = Tape(ctx, self.dw, wgrad=False)
+        td3 = Tape(ctx, self.dw, wgrad=False, devcache=devc)
         yv = Var(y.v)
         p, seed = discriminator_forward(td3, yv, True, self.u)                                   # renormalisation 3
         self.dw = td3.w
         adv, dp = bce_mean(np.ones_like(p), p)
         seed(dp)
         td3.backward()
-        tv = Tape(ctx, self.vw, wgrad=False)
+        tv = Tape(ctx, self.vw, wgrad=False, devcache=self._vggc)
         fr = vgg19_features(tv, Var(hr_t, need=False))
         tv.ops = []
         yv2 = Var(y.v)
