@@ -294,8 +294,31 @@ class ESRGANTrainer:
         self.allreduce = allreduce                        # data parallel: callable(dict of host grads) -> averaged dict (RCCL / gloo)
 
     def _host(self, grads):
-        return {n: (np.asarray(a.cpu().numpy() if isinstance(a, torch.Tensor) else a, np.float32),
-                    np.asarray(b.cpu().numpy() if isinstance(b, torch.Tensor) else b, np.float32)) for n, (a, b) in grads.items()}
+        """{layer: [dk, db]} (device tensors, or host arrays for the discriminator's dense head) -> host fp32 arrays; the device ones
+        cross PCIe as ONE flat buffer."""
+        dev = [(n, s) for n, pair in grads.items() for s in (0, 1) if isinstance(pair[s], torch.Tensor)]
+        out = {n: [None, None] for n in grads}
+        if dev:
+            flat = torch.cat([grads[n][s].reshape(-1) for n, s in dev]).cpu().numpy()
+            o = 0
+            for n, s in dev:
+                t = grads[n][s]
+                out[n][s] = flat[o:o + t.numel()].reshape(tuple(t.shape))
+                o += t.numel()
+        for n, pair in grads.items():
+            for s in (0, 1):
+                if out[n][s] is None:
+                    out[n][s] = np.asarray(pair[s], np.float32)
+        return {n: (a, b) for n, (a, b) in out.items()}
+
+    def _upload(self, weights, cache):
+        """All arrays of a parameter dict in one host-to-device copy; `cache` (Tape.devcache) then maps every array to its view."""
+        arrs = [a for pair in weights.values() for a in pair]
+        flat = self.ctx.to_device(np.concatenate([np.asarray(a, np.float32).ravel() for a in arrs]))
+        o = 0
+        for a in arrs:
+            cache[id(a)] = (a, flat[o:o + a.size].view(tuple(a.shape)))
+            o += a.size
 
     def train_step(self, lr_images, hr_images):
         """-> {'g_loss', 'd_loss', parts...}; weights, u, optimiser states advance in place (ESRGAN_model.py:475-533)."""
@@ -304,6 +327,8 @@ class ESRGANTrainer:
         devc = {}                                          # device copies of this step's parameter arrays (one upload per array)
         if not hasattr(self, "_vggc"):
             self._vggc = {}                                # the frozen VGG19 stays on the device
+            self._upload(self.vw, self._vggc)
+        self._upload(self.gw, devc)
         # ---- discriminator update
         tg = Tape(ctx, self.gw, wgrad=False, devcache=devc)
         fake = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att).v
