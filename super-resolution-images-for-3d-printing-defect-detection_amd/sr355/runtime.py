@@ -154,13 +154,15 @@ class Context:
                                       y.data_ptr(), self.stream()))
         return y
 
-    def conv2d_dev(self, x, w_dev, b_dev, cout, rot=False, act="linear", d2s=1):
+    def conv2d_dev(self, x, w_dev, b_dev, cout, rot=False, act="linear", d2s=1, alpha=1.0, skip1=None, beta1=0.0):
         """conv2d with DEVICE fp32 weights: w_dev [K,K,Cin,Cout], or with rot=True the forward kernel [K,K,Cout,Cin] of the layer whose
         input gradient is wanted.  Packs on the device, asynchronous (sr_conv2d_dev)."""
         _check_tensor(self, x, "conv2d_dev input")
         _check_tensor(self, w_dev, "conv2d_dev kernel")
         if b_dev is not None:
             _check_tensor(self, b_dev, "conv2d_dev bias")
+        if skip1 is not None:
+            _check_tensor(self, skip1, "conv2d_dev skip1")
         B, H, W, Cx = x.shape
         k = w_dev.shape[0]
         want = (k, k, cout, Cx) if rot else (k, k, Cx, cout)
@@ -170,7 +172,8 @@ class Context:
         y = self.empty((B, H * r, W * r, cout // (r * r)), torch.float32)
         actc = {"linear": L.ACT_LINEAR, None: L.ACT_LINEAR, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH}[act]
         self.check(self.lib.sr_conv2d_dev(self.h, x.data_ptr(), B, H, W, Cx, w_dev.data_ptr(), None if b_dev is None else b_dev.data_ptr(), k,
-                                          int(cout), int(bool(rot)), actc, 1.0, None, 0.0, None, 0.0, 0, r, y.data_ptr(), self.stream()))
+                                          int(cout), int(bool(rot)), actc, float(alpha), None if skip1 is None else skip1.data_ptr(), float(beta1),
+                                          None, 0.0, 0, r, y.data_ptr(), self.stream()))
         return y
 
     def self_attention(self, x, wf, bf, wg, bg, wh, bh, wv, bv):

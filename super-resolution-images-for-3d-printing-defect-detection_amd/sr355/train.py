@@ -22,6 +22,28 @@ def _rot(w):
     return np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))
 
 
+class DevWeights:
+    """A parameter dict on the device for one optimiser step: one flat upload, per-array views; conv / dgrad run on them through
+    sr_conv2d_dev (packed into MFMA fragment order by a device kernel, no host re-pack per call)."""
+
+    def __init__(self, ctx, w):
+        self.ctx = ctx
+        arrs = [(n, s, np.asarray(a, np.float32)) for n, pair in w.items() for s, a in enumerate(pair)]
+        flat = ctx.to_device(np.concatenate([a.ravel() for _, _, a in arrs]))
+        self.t, o = {}, 0
+        for n, s, a in arrs:
+            self.t[(n, s)] = flat[o:o + a.size].view(tuple(a.shape))
+            o += a.size
+
+    def conv(self, x, name, **kw):
+        k = self.t[(name, 0)]
+        return self.ctx.conv2d_dev(x, k, self.t[(name, 1)], k.shape[3], **kw)
+
+    def dgrad(self, dy, name):
+        k = self.t[(name, 0)]
+        return self.ctx.conv2d_dev(dy, k, None, k.shape[2], rot=True)
+
+
 class Adam:
     """keras.optimizers.Adam (TF 2.10 optimizer_v2), dense update, fp32 state."""
 
@@ -56,16 +78,17 @@ class Adam:
 # ---------------------------------------------------------------------------------------------------------------- graphs
 def srcnn_loss_and_grads(ctx, w, x, t):
     """SRCNN_model.py:48-53 + mean_squared_error.  x, t device fp32 [B,H,W,3].  -> (prediction, loss tensor [1], {layer: (dw, db)})."""
-    a1 = ctx.conv2d(x, *w["conv2d"], act="relu")
-    a2 = ctx.conv2d(a1, *w["conv2d_1"], act="relu")
-    y = ctx.conv2d(a2, *w["conv2d_2"])
+    dw = DevWeights(ctx, w)
+    a1 = dw.conv(x, "conv2d", act="relu")
+    a2 = dw.conv(a1, "conv2d_1", act="relu")
+    y = dw.conv(a2, "conv2d_2")
     loss = ctx.mse(t, y)
     g = {}
     dy = ctx.eltwise(L.ELT_AXPBY, y, t, 2.0 / y.numel(), -2.0 / y.numel())
     g["conv2d_2"] = ctx.conv2d_wgrad(a2, dy, 5)
-    d2 = ctx.eltwise(L.ELT_RELU_BWD, ctx.conv2d(dy, _rot(w["conv2d_2"][0])), a2)
+    d2 = ctx.eltwise(L.ELT_RELU_BWD, dw.dgrad(dy, "conv2d_2"), a2)
     g["conv2d_1"] = ctx.conv2d_wgrad(a1, d2, 1)
-    d1 = ctx.eltwise(L.ELT_RELU_BWD, ctx.conv2d(d2, _rot(w["conv2d_1"][0])), a1)
+    d1 = ctx.eltwise(L.ELT_RELU_BWD, dw.dgrad(d2, "conv2d_1"), a1)
     g["conv2d"] = ctx.conv2d_wgrad(x, d1, 9)
     return y, loss, g
 
@@ -75,44 +98,45 @@ def edsr_loss_and_grads(ctx, w, x, t, scale=2, num_res_blocks=16, res_scaling=0.
     names = ["conv2d"] + [f"conv2d_{i}" for i in range(1, 2 * num_res_blocks + 5)]
     it = iter(names)
     n_head = next(it)
-    h0 = ctx.conv2d(x, *w[n_head])
+    dw = DevWeights(ctx, w)
+    h0 = dw.conv(x, n_head)
     cur, blocks = h0, []
     for _ in range(num_res_blocks):
         na, nb = next(it), next(it)
-        tt = ctx.conv2d(cur, *w[na], act="relu")
-        nxt = ctx.conv2d(tt, *w[nb], alpha=res_scaling, skip1=cur, beta1=1.0)
+        tt = dw.conv(cur, na, act="relu")
+        nxt = dw.conv(tt, nb, alpha=res_scaling, skip1=cur, beta1=1.0)
         blocks.append((na, nb, cur, tt))
         cur = nxt
     n_body = next(it)
-    body = ctx.conv2d(cur, *w[n_body], skip1=h0, beta1=1.0)
+    body = dw.conv(cur, n_body, skip1=h0, beta1=1.0)
     ups, up = [], body
     for r in ([scale] if scale in (2, 3) else [2, 2]):
         nu = next(it)
-        v = ctx.conv2d(up, *w[nu], d2s=r)
+        v = dw.conv(up, nu, d2s=r)
         ups.append((nu, up, r))
         up = v
     n_out = next(it)
-    pre = ctx.conv2d(up, *w[n_out])
+    pre = dw.conv(up, n_out)
     y = ctx.eltwise(L.ELT_CLIP01, pre)
     loss = ctx.mse(t, y)
     g = {}
     dy = ctx.eltwise(L.ELT_AXPBY, y, t, 2.0 / y.numel(), -2.0 / y.numel())
     dpre = ctx.eltwise(L.ELT_CLIP01_BWD, dy, pre)
     g[n_out] = ctx.conv2d_wgrad(up, dpre, 3)
-    d = ctx.conv2d(dpre, _rot(w[n_out][0]))
+    d = dw.dgrad(dpre, n_out)
     for nu, uin, r in reversed(ups):
         dv = ctx.space_to_depth(d, r)
         g[nu] = ctx.conv2d_wgrad(uin, dv, 3)
-        d = ctx.conv2d(dv, _rot(w[nu][0]))
+        d = dw.dgrad(dv, nu)
     d_h0 = d                                                  # global skip: body = conv(cur) + h0
     g[n_body] = ctx.conv2d_wgrad(cur, d, 3)
-    d = ctx.conv2d(d, _rot(w[n_body][0]))
+    d = dw.dgrad(d, n_body)
     for na, nb, cin, tt in reversed(blocks):
         du = ctx.eltwise(L.ELT_AXPBY, d, None, res_scaling, 0.0)
         g[nb] = ctx.conv2d_wgrad(tt, du, 3)
-        dt = ctx.eltwise(L.ELT_RELU_BWD, ctx.conv2d(du, _rot(w[nb][0])), tt)
+        dt = ctx.eltwise(L.ELT_RELU_BWD, dw.dgrad(du, nb), tt)
         g[na] = ctx.conv2d_wgrad(cin, dt, 3)
-        d = ctx.eltwise(L.ELT_AXPBY, d, ctx.conv2d(dt, _rot(w[na][0])), 1.0, 1.0)
+        d = ctx.eltwise(L.ELT_AXPBY, d, dw.dgrad(dt, na), 1.0, 1.0)
     d = ctx.eltwise(L.ELT_AXPBY, d, d_h0, 1.0, 1.0)
     g[n_head] = ctx.conv2d_wgrad(x, d, 3)
     return y, loss, g
