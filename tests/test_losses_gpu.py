@@ -98,5 +98,5 @@ def test_generator_loss_and_evaluate_avg_g_loss(ctx):
     r1 = M.generator_loss(hr[:2], fake[:2], m.d_weights, m.vgg_weights, dtype=np.float64)[0]
     r2 = M.generator_loss(hr[2:], fake[2:], m.d_weights, m.vgg_weights, dtype=np.float64)[0]
     assert abs(ev["avg_g_loss"] - 0.5 * (r1 + r2)) <= 1e-4 * max(1.0, abs(r1))      # mean of per-batch means (Appendix C.8)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                       # fit exists now (tests/test_train_gpu.py); without data it raises as the reference does
         m.fit()
