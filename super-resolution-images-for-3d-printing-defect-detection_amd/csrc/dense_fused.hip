@@ -428,19 +428,18 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             if (MODE == 1 && c < 2) {
                 // the block's own input x (channels [0,64) = chunks 0,1) is layer 1's skip: fold xscale * x(centre pixel) into the accumulators
                 // of cout blocks 2c, 2c+1 from the staged image (row j = w+1)
-                const float sc = p.xscale;
+                // (branch-free in c: a run-time choice of the accumulator block made hipcc merge the accumulators through phis and copy them)
+                const float sc0 = c == 0 ? p.xscale : 0.f, sc1 = c == 0 ? 0.f : p.xscale;
 #pragma unroll
                 for (int cg = 0; cg < 3; ++cg)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int slice = h * 2 + (q >> 1);
                         const bf16x4 xk = *reinterpret_cast<const bf16x4*>(sb + (wave + 1) * ROWB + cg * 1024 + 64 * px + 16 * (slice ^ (2 * ((px >> 2) & 1))) + (q & 1) * 8);
-                        if (c == 0) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) a1[h][cg][e] += sc * (float)xk[e];
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) a1[2 + h][cg][e] += sc * (float)xk[e];
+                        for (int e = 0; e < 4; ++e) {
+                            a1[h][cg][e] += sc0 * (float)xk[e];
+                            a1[2 + h][cg][e] += sc1 * (float)xk[e];
                         }
                     }
             }
