@@ -56,10 +56,15 @@ constexpr int NSTG = 11;               // staged rows per chunk: stream rows [8s
 constexpr int STGB = NSTG * ROWB;
 constexpr int WINR = 10;               // ring rows of layer 0's output: [8s-2, 8s+8)
 
-template <int NB0, int NB1> struct ChainLds {
+template <int NB0, int NB1, int MODE> struct ChainLds {
     static constexpr int WSLOT = (NB0 + NB1) * 3 * 1024;
-    static constexpr int NWS = 3;                                             // weight ring slots: the loaders run two granules ahead
-    static constexpr int BYTES = 2 * STGB + WINR * ROWB + NWS * WSLOT + (NB0 + NB1) * 16 * 4;
+    // Tail: two staging buffers (next chunk's rows fly during this chunk), three weight slots (the loaders' DMA runs two granules
+    // ahead).  Growth pairs: their weights are register-resident in the loader waves (ds_write, one granule ahead: two slots), which
+    // frees the room for a THIRD staging buffer -- rows are requested two chunks ahead, so a row piece has a whole chunk (~7 k
+    // cycles) more than HBM's latency to land before anybody waits for it.
+    static constexpr int NSB = MODE == 0 ? 3 : 2;
+    static constexpr int NWS = MODE == 0 ? 2 : 3;
+    static constexpr int BYTES = NSB * STGB + WINR * ROWB + NWS * WSLOT + (NB0 + NB1) * 16 * 4;
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -96,14 +101,15 @@ constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + 
 // staging buffers (all that fits beside the ring in 160 KiB) let the loaders run ahead.
 template <int EXT, int NB0, int NB1, int MODE, bool HAS_O, bool STAMP>
 __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4) chain2_kernel(ChainParams p) {
-    using L = ChainLds<NB0, NB1>;
+    using L = ChainLds<NB0, NB1, MODE>;
     constexpr int NBT = NB0 + NB1, WSLOT = L::WSLOT;
     constexpr int NGR = 3 * (EXT + 1);                 // granules per step: (chunk, kx) for the EXT external chunks + layer 0's own chunk
     constexpr int EXTG = 3 * EXT;
     constexpr int NTHR = (NCOMP + NLOAD) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const stg = smem;
-    char* const win = smem + 2 * STGB;
+    constexpr int NSB = L::NSB;
+    char* const win = smem + NSB * STGB;
     char* const wr = win + WINR * ROWB;
     constexpr int NWS = L::NWS;
     float* const lbias = reinterpret_cast<float*>(wr + NWS * WSLOT);
@@ -245,11 +251,14 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             }
             return n;
         };
-        // prologue: weights of granules 0 and 1, external chunk 0 of step 0; all of it is waited for before the first barrier
-        put_weights(std::integral_constant<int, 0>{}, 0, true);
-        put_weights(std::integral_constant<int, 1>{}, 1, true);
-        for (int k = lw; k < 33; k += NLOAD) stage_piece(0, 0, k, stg);
-        int nch = 0, prev_stage = 0;
+        // prologue: weights of the first WL granules, the first SL external chunks of step 0; all of it is waited for before the first barrier
+        constexpr int WL = NWS - 1;                                      // weights run WL granules ahead
+        constexpr int SL = NSB - 1;                                      // rows run SL chunks ahead
+        static_assert(MODE == 1 || (RT_E * NLOAD >= NBT * 3 && RT_R * NLOAD >= NB1 * 3), "growth pairs: every weight piece is resident (no weight DMA in the counted waits)");
+        static_for<WL>([&](auto I) { put_weights(I, decltype(I)::value, true); });
+        for (int c0 = 0; c0 < SL; ++c0)
+            for (int k = lw; k < 33; k += NLOAD) stage_piece(0, c0, k, stg + c0 * STGB);
+        int nch = 0, prev_stage = 0, prev_stage2 = 0;
         for (int s = 0; s < nsteps; ++s) {
             static_for<NGR>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -259,29 +268,35 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the resident pieces written in the previous iteration
                 __builtin_amdgcn_s_barrier();
                 CHAIN_STAMP(1);
-                constexpr int i2 = (i + 2) % NGR;                        // granule G+2
-                const bool wlive = i + 2 < NGR || s + 1 < nsteps;
+                constexpr int i2 = (i + WL) % NGR;                       // granule G+WL
+                const bool wlive = i + WL < NGR || s + 1 < nsteps;
                 constexpr int kxi = i < EXTG ? i % 3 : -1;
-                // vmcnt retires in order, so the order of issue decides what the counted wait can leave in flight.  What the next barrier
-                // must publish: the weights of granule G+1 (issued FIRST in the previous iteration) and, after the third granule of a chunk,
+                // vmcnt retires in order, so the order of issue decides what the counted wait can leave in flight.  Tail: the next barrier
+                // must publish the weights of granule G+1 (issued FIRST in the previous iteration) and, after the third granule of a chunk,
                 // all of the next chunk's rows.  Granules 0 / 1 of a chunk: weights, then rows; wait for all but (the previous iteration's
-                // rows + everything of this one).  Granule 2: rows first, then weights; wait for all but these weights.
+                // rows + everything of this one).  Granule 2: rows first, then weights; wait for all but these weights.  Growth pairs: no
+                // weight DMA; the rows needed next were issued at least three iterations ago: wait for all but the last three iterations'.
                 int nw_dma = 0, nst = 0;
-                if (kxi != 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + 2, wlive);
+                if (kxi != 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + WL, wlive);
                 if constexpr (i < EXTG) {
                     constexpr int c = i / 3, kx = i - 3 * c;
-                    int c1 = c + 1, s2 = s;
-                    if (c1 == EXT) { c1 = 0; s2 = s + 1; }
+                    int c1 = c + SL, s2 = s;
+                    if (c1 >= EXT) { c1 -= EXT; s2 = s + 1; }
                     if (s2 < nsteps) {
-                        char* sdst = stg + ((nch + 1) & 1) * STGB;
+                        char* sdst = stg + ((nch + SL) % NSB) * STGB;
                         for (int k = 11 * kx + lw; k < 11 * kx + 11; k += NLOAD, ++nst) stage_piece(s2, c1, k, sdst);
                     }
                     if (kx == 2) ++nch;
                 }
-                if (kxi == 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + 2, wlive);
+                if (kxi == 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + WL, wlive);
                 CHAIN_STAMP(2);
-                wait_all_but(kxi == 2 ? nw_dma : nw_dma + nst + prev_stage);
-                prev_stage = kxi == 2 ? 0 : nst;
+                if (MODE == 0) {
+                    wait_all_but(nst + prev_stage + prev_stage2);
+                    prev_stage2 = prev_stage; prev_stage = nst;
+                } else {
+                    wait_all_but(kxi == 2 ? nw_dma : nw_dma + nst + prev_stage);
+                    prev_stage = kxi == 2 ? 0 : nst;
+                }
                 CHAIN_STAMP(3);
                 ++G;
             });
@@ -411,7 +426,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
 
 #pragma nounroll
         for (int c = 0; c < EXT; ++c, ++nch) {
-            const char* sb = stg + (nch & 1) * STGB;
+            const char* sb = stg + (nch % NSB) * STGB;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx, ++G) {
                 CHAIN_STAMP(0);
@@ -476,7 +491,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 }
             }
         }
-        char* const tb = stg + ((nch + 1) & 1) * STGB + wave * 4096;       // transposition slots (free staging buffer, see above)
+        char* const tb = stg + ((nch + NSB - 1) % NSB) * STGB + wave * 4096;       // transposition slots (free staging buffer, see above)
         // the other skip tensor of an RRDB's last block (beta_o * so) is folded into layer 1's accumulators as (beta_o / alpha) * so while
         // layer 1 runs on the ring: column group kx's two 16-byte loads are issued around the barrier of ring granule kx (early waves
         // behind it, late waves in front of it) and consumed after that granule's MFMAs -- eight registers for one granule
@@ -563,7 +578,7 @@ uint16_t bf16_host(float f) {
 
 template <int EXT, int NB0, int NB1, int MODE>
 int launch_chain(sr_ctx* ctx, const ChainParams& p, bool has_o, int nwg, hipStream_t st) {
-    constexpr int lds = ChainLds<NB0, NB1>::BYTES;
+    constexpr int lds = ChainLds<NB0, NB1, MODE>::BYTES;
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (p.dbg) {                                  // diagnostic stamped variant (never in production)
         auto k = chain2_kernel<EXT, NB0, NB1, MODE, MODE == 1, true>;
