@@ -119,6 +119,15 @@ class ESRGAN(DeviceModelMixin):
             self.g_optimizer, self.d_optimizer = self._trainer.g_opt, self._trainer.d_opt
         return self._trainer
 
+    def enable_data_parallel(self):
+        """One process per GPU (torch.distributed initialised, RCCL): every rank feeds fit() its own shard of each batch and the
+        gradients of both networks are averaged as one flat bucket per optimiser step (sr355.dist.allreduce_mean_grads).  Seeded
+        initial weights and spectral-norm vectors are identical on every rank, so the replicas stay in step.  Call before fit()."""
+        from sr355 import dist as D
+        self.grad_allreduce = lambda grads: D.allreduce_mean_grads(grads, device=self.ctx.torch_device)
+        if getattr(self, "_trainer", None) is not None:
+            self._trainer.allreduce = self.grad_allreduce
+
     def _sync_from_trainer(self):
         tr = self._trainer
         self.set_weights(tr.gw)
