@@ -329,9 +329,12 @@ class ESRGANTrainer:
             self._vggc = {}                                # the frozen VGG19 stays on the device
             self._upload(self.vw, self._vggc)
         self._upload(self.gw, devc)
+        # The reference runs the generator twice per step, once under each tape (ESRGAN_model.py:490, :508); its weights do not change
+        # in between (the discriminator is updated first), so both runs are the same tensor: one taped forward serves both.
+        tg = Tape(ctx, self.gw, devcache=devc)
+        y = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att)
+        fake = y.v
         # ---- discriminator update
-        tg = Tape(ctx, self.gw, wgrad=False, devcache=devc)
-        fake = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att).v
         td = Tape(ctx, self.dw, devcache=devc)
         p_real, seed_real = discriminator_forward(td, Var(hr_t, need=False), True, self.u)       # renormalisation 1
         l_real, dp = bce_mean(np.ones_like(p_real), p_real)
@@ -350,9 +353,6 @@ class ESRGANTrainer:
         self.d_opt.lr = staircase_lr(self.d_lr0, self.step)
         self.dw = self.d_opt.apply(self.dw, d_grads)
         # ---- generator update
-        tg = Tape(ctx, self.gw, devcache=devc)
-        x = Var(lr_t, need=False)
-        y = generator_forward(tg, x, self.scale, self.nb, self.att)
         td3 = Tape(ctx, self.dw, wgrad=False, devcache=devc)
         yv = Var(y.v)
         p, seed = discriminator_forward(td3, yv, True, self.u)                                   # renormalisation 3
