@@ -6,7 +6,7 @@
 //   conv4 + conv5 (the pair that owns 65 % of a block's FLOP): 160 + 32 + 192 + 64 channel reads/writes -> 160 + 64.
 //
 // Shape of the computation (W = 48 exactly: three 16-pixel column groups; any H; any batch):
-//   * a workgroup (8 waves, one per CU) owns a contiguous run of images and walks them top to bottom as ONE stream of rows,
+//   * a workgroup (12 waves, one workgroup per CU) owns a contiguous run of images and walks them top to bottom as ONE stream of rows,
 //     8 rows per step, with a zero separator row between images (it is the bottom padding of one image and the top padding
 //     of the next, so the MFMA loops never branch on image borders);
 //   * line-buffer skew: in step s the first conv (layer 0) produces stream rows [8s, 8s+8), the second (layer 1) rows
@@ -15,17 +15,20 @@
 //   * wave w owns row 8s+w of layer 0 and row 8s+w-1 of layer 1, all 48 columns, all output channels: the pixel fragment of
 //     an input row feeds both layers and all three ky taps it takes part in (0.56 LDS fragment reads per MFMA);
 //   * the external input (the dense block's concat buffer, row-blocked [B][H][C/32][W][32]: conv_common.h) is streamed one
-//     32-channel chunk at a time: 11 rows x 3 KiB per chunk land in one of two LDS buffers by LDS-DMA
-//     (global_load_lds_dwordx4, source-side XOR swizzle so that ds_read_b128 is conflict free) while the previous chunk
-//     multiplies; weights stream through a two-slot LDS ring in (chunk, kx) granules, host-packed in the order they are used;
-//   * one s_barrier per granule (54 MFMAs per wave): a granule's DMA is issued a whole granule ahead and retired with
-//     s_waitcnt vmcnt(0) just before the barrier that publishes it.
-// LDS: 2 x 33 KiB staging + 30 KiB ring + 2 x 18 KiB weights = 132 KiB -> one workgroup per CU, two waves per SIMD (the second
-// wave's MFMAs cover the first one's DMA issue and LDS latency).
+//     32-channel chunk at a time: 11 rows x 3 KiB per chunk land in one of two (tail) / three (growth pairs) LDS buffers by LDS-DMA
+//     (global_load_lds_dwordx4, source-side XOR swizzle so that ds_read_b128 is conflict free) while earlier chunks multiply;
+//     weights go through a ring of LDS slots in (chunk, kx) granules, host-packed in the order they are used;
+//   * roles: 8 compute waves (one stream row each; MFMAs, LDS reads, epilogues) + 4 loader waves (the whole DMA stream, one or two
+//     granules / chunks ahead, counted vmcnt; they also hold part -- for the growth pairs all -- of the weights in their registers for
+//     the whole kernel and put them into the slots with ds_write_b128); one s_barrier per granule (54 MFMAs per compute wave);
+//   * output rows leave through an LDS transposition (whole cache lines instead of 64 16-byte fragments per store instruction).
+// LDS: tail 2 x 33 + 30 + 3 x 18 KiB = 150 KiB, pairs 3 x 33 + 30 + 2 x 12 = 153 KiB -> one workgroup per CU, three waves per SIMD.
+// What bounds the kernels is the CU's vector-memory path (~16-21 B/clk in, ~12 B/clk out): DESIGN.md 3.3 has the measurements.
 //
 // Epilogues: layer 0 = bias + ReLU -> bf16 -> LDS ring (+ global when a later kernel needs it); layer 1 = either the same
 // (growth conv) or the block's tail  alpha*(conv5 + b) + x [+ rrdb_in]  with x folded in from the staged chunk (the same
-// "skip from LDS" identity as conv_rows.hip) and written to channels [0,64) of the next block's buffer.
+// "skip from LDS" identity as conv_rows.hip), rrdb_in folded in during the ring granules, written to channels [0,64) of the next
+// block's buffer.
 #include <stdlib.h>
 #include <string.h>
 
@@ -96,9 +99,9 @@ constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + 
 // vmcnt): barrier -> issue -> wait for the previous iteration's pieces -> barrier; the eight compute waves go barrier -> MFMAs ->
 // barrier and touch vector memory only in the epilogues.  Measured and not kept: 6 / 8 loaders (same port time, compute waves
 // slower at 4 waves per SIMD and 128 registers), compute waves issuing 16 of a granule's 18 weight pieces (-10 %: everybody queues
-// on the port right after the barrier).  What bounds the kernel now is that path: 29-35 KiB per granule at ~20-25 B/clk is
-// 1.4-1.75 k cycles against 1.73 k cycles of MFMA per granule, and the two overlap only as far as three weight slots and two
-// staging buffers (all that fits beside the ring in 160 KiB) let the loaders run ahead.
+// on the port right after the barrier).  That path bounds the kernel (a piece from L2 ~47 cycles, from HBM ~130, the same with the MFMA
+// bodies skipped and with 8 or 252 workgroups on the chip), so everything since has been about moving fewer bytes through it: resident
+// weights in the loaders' spare registers, whole-line stores, an even number of pieces per iteration (below).
 template <int EXT, int NB0, int NB1, int MODE, bool HAS_O, bool STAMP>
 __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4) chain2_kernel(ChainParams p) {
     using L = ChainLds<NB0, NB1, MODE>;
@@ -137,21 +140,6 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     auto dma = [&](const char* src, char* dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    // Weight pieces of the granule with running number Gw at position iw of its step: pieces [0, WCOMP) are issued by the compute
-    // waves (two each at most -- a piece costs the issuing wave ~230 cycles, which its SIMD partner covers with MFMAs), the rest by the
-    // loaders; `first`, `stride`: this wave's share.  Returns the number issued.
-    constexpr int WCOMP = 0;                   // all pieces belong to the loaders (see "Roles" above)
-    auto weights_of = [&](int Gw, int iw, bool live, int first, int stride, int lo, int hi) -> int {
-        if (!live) return 0;
-        const bool ext = iw < EXTG;
-        const int nw = min(ext ? NBT * 3 : NB1 * 3, hi);
-        const char* wsrc = p.w + (ext ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024));
-        char* wdst = wr + (Gw % NWS) * WSLOT;
-        int n = 0;
-        for (int k = lo + first; k < nw; k += stride, ++n) dma(wsrc + k * 1024 + lane * 16, wdst + k * 1024);
-        return n;
-    };
-    auto next_pos = [&](int& s_, int& i_) { if (++i_ == NGR) { i_ = 0; ++s_; } };
     auto wait_all_but = [&](int n) {          // s_waitcnt vmcnt(n): everything but this wave's n youngest vector-memory operations has completed
         switch (n) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -401,16 +389,11 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             for (int cg = 0; cg < 3; ++cg) xc[cg] = xn[cg];
         }
     };
-    // Granule boundary of a compute wave: its LDS reads / writes of the finished granule are done, the weight pieces it issued one
-    // granule ago have landed (counted wait: the ones it issued in the granule just finished stay in flight); then the barrier that
-    // publishes everybody's pieces; then its share of the weights two granules ahead.
-    int s2w = 0, i2w = 1, mine = 0;
+    // Granule boundary of a compute wave: its LDS reads / writes of the finished granule are done, then the barrier that publishes the
+    // loaders' pieces.  No vmcnt here: a compute wave issues no DMA, and its epilogue stores drain on their own.
     auto sync = [&]() {
-        if (WCOMP > 0) wait_all_but(mine);   // only the DMA pieces a compute wave issued itself need its vmcnt; its epilogue stores drain on their own
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        next_pos(s2w, i2w);
-        mine = weights_of(G + 2, i2w, s2w < nsteps, wave, NCOMP, 0, WCOMP);
     };
 
     int nch = 0;
