@@ -266,3 +266,39 @@ def esrgan_train_step_ref(gw, dw, u, vw, lr_img, hr_img, scale, num_rrdb, attent
               "spectral": val(spec)}
     return dict(losses=losses, g_grads=g_grads, d_grads=d_grads, gw=gw, dw=dw, u=u, g_opt=g_opt, d_opt=d_opt,
                 dy=dy, y=y.detach().permute(0, 2, 3, 1).numpy())
+
+
+# =====================================================================================================================
+# FineTunedVGG16.fit with the default frozen base (VGG16_model.py:84-97, :111-157): the two Dense layers, torch autograd fp64
+# =====================================================================================================================
+def vgg16_head_fit_ref(g_train_batches, g_val, y_val, w, lr=1e-3, l2_reg=0.0):
+    """g_train_batches: [[(features [n,512], labels)] per epoch] (no dropout: deterministic).  -> (head weights fp64, history dict)."""
+    head = {n: (np.asarray(w[n][0], np.float64), np.asarray(w[n][1], np.float64)) for n in ("dense", "predictions")}
+    opt = AdamRef(head, lr)
+    hist = {"loss": [], "accuracy": [], "val_loss": [], "val_accuracy": []}
+
+    def forward(p, g):
+        h = torch.relu(torch.tensor(np.asarray(g, np.float64)) @ p["dense"][0] + p["dense"][1])
+        return torch.softmax(h @ p["predictions"][0] + p["predictions"][1], dim=1)
+
+    def cce(prob, y):
+        pc = torch.clamp(prob[torch.arange(len(y)), torch.tensor(np.asarray(y, np.int64))], 1e-7, 1.0 - 1e-7)
+        return torch.mean(-torch.log(pc))
+
+    for batches in g_train_batches:
+        tot, n = np.zeros(2), 0
+        for g, y in batches:
+            p = _params(head)
+            prob = forward(p, g)
+            loss = cce(prob, y) + l2_reg * (p["dense"][0] ** 2).sum()
+            loss.backward()
+            tot += [float(loss.item()) * len(y), float((prob.argmax(dim=1).numpy() == np.asarray(y)).mean()) * len(y)]
+            n += len(y)
+            head = opt.apply(head, _grads(p))
+        with torch.no_grad():
+            p = {k: (torch.tensor(a), torch.tensor(b)) for k, (a, b) in head.items()}
+            prob = forward(p, g_val)
+            vl = float((cce(prob, y_val) + l2_reg * (p["dense"][0] ** 2).sum()).item())
+            va = float((prob.argmax(dim=1).numpy() == np.asarray(y_val)).mean())
+        hist["loss"].append(tot[0] / n); hist["accuracy"].append(tot[1] / n); hist["val_loss"].append(vl); hist["val_accuracy"].append(va)
+    return head, hist

@@ -34,6 +34,9 @@ class FineTunedVGG16(DeviceModelMixin):
         weights = load_pretrained(pretrained_path) if from_pretrained else None
         if weights is not None:
             num_classes = int(weights["predictions"][0].shape[-1])
+        self.base_trainable, self.dropout_rate, self.l2_reg, self.learning_rate = bool(base_trainable), float(dropout_rate), float(l2_reg), float(learning_rate)
+        if loss != "sparse_categorical_crossentropy":
+            raise ValueError("only sparse_categorical_crossentropy (the reference's default, VGG16_model.py:29) is built")
         self._make("vgg16", self.compute_dtype, num_classes=num_classes)
         if weights is not None:
             self.set_weights(weights)
@@ -41,8 +44,79 @@ class FineTunedVGG16(DeviceModelMixin):
         else:
             self._random_init(seed=4000)
 
-    def fit(self, *args, **kwargs):
-        raise NotImplementedError("classifier training is outside this round's hot path")
+    # ------------------------------------------------------------------ training of the head on the frozen base (VGG16_model.py:111-166)
+    def _gap_features(self, images, batch_size=256):
+        """[n,H,W,3] in [0,1] -> [n,512]: the frozen conv base on the device (tap after block5_conv3), max-pool and GAP kernels."""
+        from sr355 import _lib as L
+        out = []
+        for i in range(0, len(images), batch_size):
+            x = self.ctx.to_device(np.asarray(images[i:i + batch_size], np.float32),
+                                   torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32)
+            _, taps = self.model.forward_with_taps(x, ["block5_conv3"])
+            f = self.ctx.spatial_op(L.SP_MAXPOOL2, taps["block5_conv3"])
+            out.append(self.ctx.spatial_op(L.SP_GAP, f).cpu().numpy().reshape(len(x), -1))
+        return np.concatenate(out) if out else np.zeros((0, 512), np.float32)
+
+    @staticmethod
+    def _augment(x, rng, rotation_range=20, width_shift_range=0.2, height_shift_range=0.2, horizontal_flip=True):
+        """One draw of keras ImageDataGenerator(rotation_range=20, width_shift_range=0.2, height_shift_range=0.2,
+        horizontal_flip=True) per image (VGG16_model.py:129-134): random rotation about the centre, random shifts as fractions of
+        the size, fill_mode 'nearest', bilinear interpolation, random flip.  A CPU step in the reference as well (NumPy / SciPy)."""
+        from scipy import ndimage
+        out = np.empty_like(x)
+        h, w = x.shape[1:3]
+        for i, img in enumerate(x):
+            th = np.deg2rad(rng.uniform(-rotation_range, rotation_range))
+            ty, tx = rng.uniform(-height_shift_range, height_shift_range) * h, rng.uniform(-width_shift_range, width_shift_range) * w
+            c, s_ = np.cos(th), np.sin(th)
+            rot = np.array([[c, -s_], [s_, c]])
+            centre = np.array([(h - 1) / 2.0, (w - 1) / 2.0])
+            offset = centre - rot @ centre + np.array([ty, tx])          # output pixel o samples input rot @ o + offset
+            for ch in range(img.shape[2]):
+                out[i, :, :, ch] = ndimage.affine_transform(img[:, :, ch], rot, offset=offset, order=1, mode="nearest")
+            if horizontal_flip and rng.random() < 0.5:
+                out[i] = out[i, :, ::-1]
+        return out
+
+    def fit(self, X_train, y_train, X_val, y_val, batch_size=32, epochs=50, use_augmentation=True, seed=42):
+        """FineTunedVGG16.fit (VGG16_model.py:111-157) for the default frozen base: the conv base runs on the device per batch, the
+        two Dense layers train on the host (Adam, sparse CCE, Dropout, EarlyStopping / ReduceLROnPlateau).  With augmentation the
+        batches are 32 images, as the reference's datagen.flow(..., batch_size=32) hard-codes."""
+        from sr355.train import fit_head
+        if self.model is None:
+            raise ValueError("Model is not built yet.")
+        if self.base_trainable:
+            raise NotImplementedError("fine-tuning the VGG16 conv layers (base_trainable=True) is not built; the default frozen base is")
+        X_train, y_train = np.asarray(X_train, np.float32), np.asarray(y_train, np.int64).reshape(-1)
+        rng = np.random.default_rng(seed)
+        bs = 32 if use_augmentation else int(batch_size)
+
+        def batches(epoch):
+            order = rng.permutation(len(X_train))
+            for i in range(0, len(order), bs):
+                idx = order[i:i + bs]
+                xb = X_train[idx]
+                yield (self._augment(xb, rng) if use_augmentation else xb), y_train[idx]
+
+        head, history = fit_head(self._gap_features, self.weights, batches, y_train, np.asarray(X_val, np.float32), np.asarray(y_val, np.int64).reshape(-1),
+                                 learning_rate=self.learning_rate, batch_size=bs, epochs=epochs, dropout_rate=self.dropout_rate, l2_reg=self.l2_reg, seed=seed)
+        w = dict(self.weights)
+        w.update(head)
+        self.set_weights(w)
+        self.trained = True
+        return history
+
+    def evaluate(self, X_test, y_test):
+        """model.evaluate -> [loss, accuracy] (VGG16_model.py:159-166)."""
+        from sr355.train import sparse_cce
+        if not self.trained:
+            raise RuntimeError("Model has not been trained.")
+        p = np.asarray(self.predict(np.asarray(X_test, np.float32)), np.float64)
+        loss, acc = sparse_cce(p, np.asarray(y_test, np.int64).reshape(-1))
+        if self.l2_reg > 0:
+            loss += self.l2_reg * float(np.sum(np.asarray(self.weights["dense"][0], np.float64) ** 2))
+        print(f"Loss: {loss:.4f}, Accuracy: {acc:.4f}")
+        return [loss, acc]
 
     def predict(self, patches, batch_size=32):
         return self.model.predict(patches, batch_size=batch_size)

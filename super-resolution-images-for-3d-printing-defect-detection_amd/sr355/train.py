@@ -265,3 +265,108 @@ def fit(ctx, weights, loss_and_grads, predict, optimizer, X_train, Y_train, X_va
                     print(f"Epoch {ep + 1}: early stopping; restoring model weights from the end of the best epoch.")
                 break
     return weights, hist, tcb, mcb
+
+
+# ---------------------------------------------------------------------------------------------------------------- classifier head
+def head_forward(g, w, training=False, dropout_rate=0.0, rng=None):
+    """GAP features [N,512] -> Dropout -> Dense256 ReLU -> Dropout -> Dense softmax (VGG16_model.py:84-97), host fp32/fp64.
+    -> (probabilities, cache for head_backward)."""
+    k1, b1 = w["dense"]
+    k2, b2 = w["predictions"]
+    keep = 1.0 - dropout_rate
+    m0 = m1 = None
+    x0 = g
+    if training and dropout_rate > 0:
+        m0 = (rng.random(g.shape) < keep) / keep
+        x0 = g * m0
+    z1 = x0 @ k1 + b1
+    a1 = np.maximum(z1, 0)
+    x1 = a1
+    if training and dropout_rate > 0:
+        m1 = (rng.random(a1.shape) < keep) / keep
+        x1 = a1 * m1
+    z2 = x1 @ k2 + b2
+    z2 = z2 - z2.max(axis=1, keepdims=True)
+    e = np.exp(z2)
+    p = e / e.sum(axis=1, keepdims=True)
+    return p, (x0, z1, x1, m1)
+
+
+def sparse_cce(p, y, eps=1e-7):
+    """keras sparse_categorical_crossentropy on probabilities (clipped to [eps, 1-eps]) -> (mean loss, accuracy)."""
+    pc = np.clip(p[np.arange(len(y)), y], eps, 1.0 - eps)
+    return float(np.mean(-np.log(pc))), float(np.mean(np.argmax(p, axis=1) == y))
+
+
+def head_backward(p, y, cache, w, l2_reg=0.0):
+    """Gradients of mean sparse-CCE (+ l2_reg * sum(dense kernel^2), VGG16_model.py:90-92) w.r.t. the two Dense layers."""
+    x0, z1, x1, m1 = cache
+    n = len(y)
+    dz2 = p.copy()
+    dz2[np.arange(n), y] -= 1.0
+    dz2 /= n
+    k2 = w["predictions"][0]
+    g = {"predictions": (x1.T @ dz2, dz2.sum(axis=0))}
+    dx1 = dz2 @ k2.T
+    da1 = dx1 * m1 if m1 is not None else dx1
+    dz1 = da1 * (z1 > 0)
+    g["dense"] = (x0.T @ dz1 + 2.0 * l2_reg * w["dense"][0], dz1.sum(axis=0))
+    return g
+
+
+def fit_head(features, w, X_train_batches, y_train, X_val, y_val, learning_rate=1e-3, batch_size=32, epochs=50, dropout_rate=0.2,
+             l2_reg=0.0, seed=42, verbose=True):
+    """model.fit of the frozen-base classifier (VGG16_model.py:111-157): Adam, sparse categorical cross-entropy, accuracy,
+    EarlyStopping(val_loss, patience 3, restore_best_weights) and ReduceLROnPlateau(val_loss, 0.5, patience 2, min_lr 1e-7).
+    features(images) -> [n,512] GAP features (the device runs the frozen conv base); X_train_batches(epoch) yields (images, labels)
+    batches of one epoch (shuffled / augmented by the caller).  -> (head weights, History)."""
+    head = {n: (np.asarray(w[n][0], np.float32), np.asarray(w[n][1], np.float32)) for n in ("dense", "predictions")}
+    opt = Adam(head, learning_rate, epsilon=1e-7)
+    rng = np.random.default_rng(seed)
+    hist = History()
+    for k in ("loss", "accuracy", "val_loss", "val_accuracy", "lr"):
+        hist.history[k] = []
+    g_val = features(X_val)
+    best, best_w, es_wait, lr_wait, lr_best = np.inf, None, 0, 0, np.inf
+    for ep in range(epochs):
+        tot, n_seen = np.zeros(2, np.float64), 0
+        for xb, yb in X_train_batches(ep):
+            yb = np.asarray(yb, np.int64)
+            p, cache = head_forward(features(xb).astype(np.float32), head, True, dropout_rate, rng)
+            loss, acc = sparse_cce(p, yb)
+            if l2_reg > 0:
+                loss += l2_reg * float(np.sum(head["dense"][0].astype(np.float64) ** 2))
+            tot += [loss * len(yb), acc * len(yb)]
+            n_seen += len(yb)
+            grads = head_backward(p, yb, cache, head, l2_reg)
+            head = opt.apply(head, {n: (a.astype(np.float32), b.astype(np.float32)) for n, (a, b) in grads.items()})
+        pv, _ = head_forward(g_val.astype(np.float32), head)
+        vl, va = sparse_cce(pv, np.asarray(y_val, np.int64))
+        if l2_reg > 0:
+            vl += l2_reg * float(np.sum(head["dense"][0].astype(np.float64) ** 2))
+        tr = tot / max(n_seen, 1)
+        for key, val in zip(("loss", "accuracy", "val_loss", "val_accuracy", "lr"), (tr[0], tr[1], vl, va, opt.lr)):
+            hist.history[key].append(float(val))
+        hist.epoch.append(ep)
+        if verbose:
+            print(f"Epoch {ep + 1}/{epochs} - loss: {tr[0]:.4f} - accuracy: {tr[1]:.4f} - val_loss: {vl:.4f} - val_accuracy: {va:.4f} - lr: {opt.lr:.2e}")
+        if vl < lr_best - 1e-4:
+            lr_best, lr_wait = vl, 0
+        else:
+            lr_wait += 1
+            if lr_wait >= 2 and opt.lr > 1e-7:
+                opt.lr = max(opt.lr * 0.5, 1e-7)
+                lr_wait = 0
+                if verbose:
+                    print(f"Epoch {ep + 1}: ReduceLROnPlateau reducing learning rate to {opt.lr}.")
+        if vl < best:
+            best, es_wait = vl, 0
+            best_w = {n: (a.copy(), b.copy()) for n, (a, b) in head.items()}
+        else:
+            es_wait += 1
+            if es_wait >= 3:
+                head = best_w
+                if verbose:
+                    print(f"Epoch {ep + 1}: early stopping; restoring model weights from the end of the best epoch.")
+                break
+    return head, hist

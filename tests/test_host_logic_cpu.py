@@ -124,3 +124,27 @@ def test_tensor_checks_in_front_of_the_abi():
         _check_tensor(fake, t.numpy(), "x")
     with pytest.raises(ValueError):
         _check_tensor(SimpleNamespace(torch_device=torch.device("meta")), t, "x")
+
+
+def test_classifier_head_gradients_against_autograd():
+    """sr355.train.head_forward / head_backward / sparse_cce (the host half of FineTunedVGG16.fit) against torch autograd in fp64,
+    L2 regulariser of the Dense256 kernel included; dropout masks scale by 1 / keep and are repeated in the backward pass."""
+    import torch
+    from sr355 import train as T
+    rng = np.random.default_rng(0)
+    g, y = rng.standard_normal((7, 512)), rng.integers(0, 3, 7)
+    w = {"dense": (rng.standard_normal((512, 256)) * 0.05, rng.standard_normal(256) * 0.1),
+         "predictions": (rng.standard_normal((256, 3)) * 0.1, rng.standard_normal(3) * 0.1)}
+    p, cache = T.head_forward(g, w)
+    loss, acc = T.sparse_cce(p, y)
+    gr = T.head_backward(p, y, cache, w, l2_reg=0.01)
+    tw = {n: (torch.tensor(a, requires_grad=True), torch.tensor(b, requires_grad=True)) for n, (a, b) in w.items()}
+    z = torch.relu(torch.tensor(g) @ tw["dense"][0] + tw["dense"][1]) @ tw["predictions"][0] + tw["predictions"][1]
+    ref = torch.nn.functional.cross_entropy(z, torch.tensor(y)) + 0.01 * (tw["dense"][0] ** 2).sum()
+    ref.backward()
+    assert abs(loss + 0.01 * np.sum(w["dense"][0] ** 2) - ref.item()) <= 1e-12 and 0 <= acc <= 1
+    for n in gr:
+        for s in (0, 1):
+            assert np.abs(gr[n][s] - tw[n][s].grad.numpy()).max() <= 1e-12
+    pd, cd = T.head_forward(g, w, training=True, dropout_rate=0.5, rng=np.random.default_rng(3))
+    assert set(np.unique(np.round(cd[0][g != 0] / g[g != 0], 6))) <= {0.0, 2.0} and np.allclose(pd.sum(axis=1), 1.0)

@@ -324,3 +324,56 @@ def test_conv2d_dev_matches_host_packed_conv(ctx, case):
         assert got.shape == (2, 13, 11, cin) and torch.equal(got, want)
     with pytest.raises(ValueError):
         ctx.conv2d_dev(x, kd, bd, cout + 1)
+
+
+def test_vgg16_fit_frozen_base(ctx, tmp_path):
+    """FineTunedVGG16.fit (VGG16_model.py:111-157) with the default frozen base: conv base on the device per batch, the two Dense
+    layers trained on the host.  Without augmentation and dropout the run is deterministic: history and final head against the
+    torch-autograd oracle fed the oracle's own GAP features; with augmentation + dropout: runs, is reproducible from its seed,
+    changes only the head, and evaluate() / the saved checkpoint agree with it."""
+    from SRModels.defect_detection_models.VGG16_model import FineTunedVGG16
+    rng = np.random.default_rng(21)
+    X, y = rng.uniform(0, 1, (20, 32, 32, 3)).astype(np.float32), rng.integers(0, 2, 20)
+    Xv, yv = rng.uniform(0, 1, (8, 32, 32, 3)).astype(np.float32), rng.integers(0, 2, 8)
+    m = FineTunedVGG16()
+    with pytest.raises(ValueError):
+        m.fit(X, y, Xv, yv)
+    m.setup_model(input_shape=(32, 32, 3), num_classes=2, dropout_rate=0.0, learning_rate=1e-3)
+    w0 = {n: (k.copy(), b.copy()) for n, (k, b) in m.weights.items()}
+    with pytest.raises(RuntimeError):
+        m.evaluate(Xv, yv)
+    hist = m.fit(X, y, Xv, yv, batch_size=8, epochs=3, use_augmentation=False, seed=5)
+    assert m.trained and len(hist.history["loss"]) == 3
+    # the oracle: same batches (same permutations), its own fp64 features
+    feats = lambda a: M.vgg16_features(a, w0, dtype=np.float64).mean(axis=(1, 2))
+    prng, batches = np.random.default_rng(5), []
+    for _ in range(3):
+        order = prng.permutation(20)
+        batches.append([(feats(X[order[i:i + 8]]), y[order[i:i + 8]]) for i in range(0, 20, 8)])
+    head, rh = OT.vgg16_head_fit_ref(batches, feats(Xv), yv, w0, lr=1e-3)
+    for k in ("loss", "val_loss"):
+        assert np.allclose(hist.history[k], rh[k], rtol=2e-4, atol=1e-6), (k, hist.history[k], rh[k])
+    assert hist.history["accuracy"] == pytest.approx(rh["accuracy"]) and hist.history["val_accuracy"] == pytest.approx(rh["val_accuracy"])
+    for n in ("dense", "predictions"):
+        assert rel_l2(m.weights[n][0] - w0[n][0], head[n][0] - w0[n][0]) <= 5e-3, n       # three epochs of Adam steps ~ lr * sign(g)
+    assert all(np.array_equal(m.weights[n][0], w0[n][0]) for n in w0 if n.startswith("block"))      # the base is frozen
+    loss, acc = m.evaluate(Xv, yv)
+    assert abs(loss - hist.history["val_loss"][-1]) <= 1e-4 and acc == pytest.approx(hist.history["val_accuracy"][-1])
+    path = m.save(str(tmp_path), "t0")
+    m2 = FineTunedVGG16()
+    m2.setup_model(input_shape=(32, 32, 3), from_pretrained=True, pretrained_path=path)
+    assert np.array_equal(np.asarray(m2.predict(Xv)), np.asarray(m.predict(Xv)))
+    # augmentation + dropout: seeded, reproducible
+    runs = []
+    for _ in range(2):
+        a = FineTunedVGG16()
+        a.setup_model(input_shape=(32, 32, 3), num_classes=2, dropout_rate=0.2)
+        h = a.fit(X, y, Xv, yv, epochs=2, use_augmentation=True, seed=9)
+        runs.append((h.history["loss"], a.weights["dense"][0].copy()))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.isfinite(runs[0][0]).all()
+    aug = FineTunedVGG16._augment(X[:4], np.random.default_rng(1))
+    assert aug.shape == X[:4].shape and aug.min() >= 0 and aug.max() <= 1 and not np.array_equal(aug, X[:4])
+    b = FineTunedVGG16()
+    b.setup_model(input_shape=(32, 32, 3), base_trainable=True)
+    with pytest.raises(NotImplementedError):
+        b.fit(X, y, Xv, yv)
