@@ -333,4 +333,9 @@ class ESRGAN(DeviceModelMixin):
         generator_path = os.path.join(directory, f"ESRGAN_generator_x{self.scale_factor}_{timestamp}.npz")
         self._save_npz(generator_path)
         print(f"Generator model saved to {generator_path}")
+        if self.d_weights is not None:        # the stored (spectrally normalised) discriminator kernels, as model.save keeps them (:990-993)
+            from sr355.weights import save_npz
+            discriminator_path = os.path.join(directory, f"ESRGAN_discriminator_x{self.scale_factor}_{timestamp}.npz")
+            save_npz(discriminator_path, self.d_weights)
+            print(f"Discriminator model saved to {discriminator_path}")
         return generator_path

@@ -1,6 +1,8 @@
 """Training rows (SURVEY.md 8f-4 and the conv backward kernels of 8f-1): the wgrad kernel and the dgrad-by-rotated-forward identity
 against torch autograd, one SRCNN / EDSR step gradient by gradient, a few Adam steps weight by weight, and `fit` end to end
 (Keras callbacks' semantics) -- oracle/train.py is the independent fp64 derivation."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -296,6 +298,13 @@ def test_esrgan_fit_wrapper(ctx, tmp_path):
     assert losses2["val_g_loss"] == [] and len(losses2["g_loss"]) == 2
     moved = max(float(np.abs(m.weights[n][0] - gw0[n][0]).max()) for n in gw0)
     assert 1e-4 < moved < 1e-2                           # six Adam steps of 1e-4
+    gpath = m.save(str(tmp_path), "t1")                  # generator and (trained) discriminator, the reference's two files
+    dpath = gpath.replace("ESRGAN_generator", "ESRGAN_discriminator")
+    assert os.path.exists(dpath)
+    m3 = ESRGAN(compute_dtype="f32")
+    m3.setup_model(scale_factor=2, from_trained=True, generator_pretrained_path=gpath, discriminator_pretrained_path=dpath, use_attention=True)
+    m3._ensure_loss_networks()
+    assert all(np.array_equal(m3.d_weights[n][0], tr.dw[n][0]) for n in tr.dw) and all(np.array_equal(m3.weights[n][0], tr.gw[n][0]) for n in tr.gw)
     sr = m.generate(X[:2] * 2 - 1)                       # the inference model carries the trained weights
     t = GT.Tape(ctx, tr.gw, wgrad=False)
     want = GT.generator_forward(t, GT.Var(ctx.to_device(X[:2] * 2 - 1), need=False), 2, 1, True).v.cpu().numpy()
