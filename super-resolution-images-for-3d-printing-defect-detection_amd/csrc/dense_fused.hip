@@ -140,6 +140,11 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     auto dma = [&](const char* src, char* dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
+    // nt (aux = 2): a line fetched with it is not kept in L2.  Used for the rows of a step that no later step reads again, so that the
+    // three halo rows the NEXT step re-reads (11 staged rows, 8 new) are what survives in the XCD's 4 MiB between two steps.
+    auto dma_nt = [&](const char* src, char* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+    };
     auto wait_all_but = [&](int n) {          // s_waitcnt vmcnt(n): everything but this wave's n youngest vector-memory operations has completed
         switch (n) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -182,7 +187,8 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             int img, y;
             const bool real = row_of(8 * s2 - 2 + j, img, y);
             const char* src = real ? p.in + (((int64_t)(img0 + img) * H + y) * p.in_nch + c1) * ROWB + pc * 1024 + lsrc : p.zero + lane * 16;
-            dma(src, sdst + j * ROWB + pc * 1024);
+            if (j < 8) dma_nt(src, sdst + j * ROWB + pc * 1024);
+            else dma(src, sdst + j * ROWB + pc * 1024);
         };
         // Schedule.  In the iteration of granule g (after the barrier that opens g) a loader issues
         //   * the weights of granule g+2 into ring slot (g+2) % 3 (last read in granule g-1), and
@@ -470,7 +476,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
 #pragma unroll
                 for (int cg = 0; cg < 3; ++cg) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(wrow + cg * 1024 + (lane >> 2) * 64 + 16 * ((lane & 3) ^ (2 * ((lane >> 4) & 1))));
-                    *reinterpret_cast<u32x4*>(grow + cg * 1024 + lane * 16) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(grow + cg * 1024 + lane * 16));
                 }
             }
         }
@@ -544,7 +550,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                         }
                         asm volatile("" ::: "memory");                 // the read-back below is of other lanes' writes: keep the order
                         const u32x4 line = *reinterpret_cast<const u32x4*>(slot + t_line);
-                        *reinterpret_cast<u32x4*>(grow + h * ROWB + cg * 1024 + lane * 16) = line;
+                        __builtin_nontemporal_store(line, reinterpret_cast<u32x4*>(grow + h * ROWB + cg * 1024 + lane * 16));
                     }
             }
         }
