@@ -899,10 +899,15 @@ int sr_conv2d_dev(sr_ctx* ctx, const void* x, int B, int H, int W, int Cin, cons
     int rc = conv_pack_weights_dev(ctx, d_w, d_bias, K, Cin, Cout, rot, &cw, st);
     if (rc) return rc;
     const int Cp = cw.thin ? cw.CinP : round_up(cw.CinP, 32);
-    void* xp = ctx->arena(ctx->dev_x, (size_t)B * H * W * Cp * 4 + 4096, st);
-    if (!xp) return SR_ERR_OOM;
-    rc = convert_pad_launch(ctx, x, SR_DTYPE_F32, (int64_t)B * H * W, Cin, xp, SR_DTYPE_F32, Cp, 1.f, 0.f, st);
-    if (rc) return rc;
+    const void* xp = x;
+    static const bool force_copy = getenv("SR355_CONV_DEV_COPY") != nullptr;   // A/B switch (diagnostic)
+    if (force_copy || Cp != Cin || ((uintptr_t)x % 16) != 0) {          // channel padding needed: a padded copy in the arena (else the conv reads x in place)
+        void* xa = ctx->arena(ctx->dev_x, (size_t)B * H * W * Cp * 4 + 4096, st);
+        if (!xa) return SR_ERR_OOM;
+        rc = convert_pad_launch(ctx, x, SR_DTYPE_F32, (int64_t)B * H * W, Cin, xa, SR_DTYPE_F32, Cp, 1.f, 0.f, st);
+        if (rc) return rc;
+        xp = xa;
+    }
     ConvEpilogue ep;
     ep.act = act; ep.alpha = alpha; ep.clip01 = clip01; ep.d2s_r = d2s_r < 1 ? 1 : d2s_r;
     if (skip1) { ep.skip1 = {skip1, Cout, 0}; ep.beta1 = beta1; }
