@@ -25,9 +25,9 @@ from sr355.weights import condition_attention, init_weights
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-local = int(os.environ.get("LOCAL_RANK", "0"))
+local = 0 if os.environ.get("SR355_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))   # SR355_ONE_DEVICE: N>1 rehearsal on a 1-GPU box
 torch.cuda.set_device(local)
-rank, world, _ = D.init_from_env()
+rank, world, _ = D.init_from_env(backend=os.environ.get("SR355_DIST_BACKEND"))                 # "gloo" only for that rehearsal
 ctx = Context.get(local)
 g = Model("esrgan_g", compute_dtype="f32", scale_factor=4, num_blocks=23, growth_channels=32, use_attention=True, ctx=ctx)
 d = Model("esrgan_d", compute_dtype="f32", ctx=ctx)
