@@ -10,12 +10,15 @@ GPU at 1/2/4/8); --scaling weak gives every rank its own 16 tiles.  value = SR o
 (max over ranks).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...          (no torchrun environment: bench.py starts the N ranks itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
 import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +37,10 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Peak BF
 
 
 CONV_TFLOP_PER_TILE = 36.48  # conv FLOP one 512x512 LR tile needs in reference patch mode (441 patches 48x48)
-N_PARITY = 2                 # LR patches of tile 0 pushed through both the GPU and the oracle for the parity object
+# LR patches of tile 0 pushed through both the GPU and the oracle for the parity object: a 4 x 4 grid over the tile's 21 x 21 patch
+# positions (corners, edges, interior), all inside the un-padded tile so that each has a true HR counterpart
+PARITY_GRID = (0, 6, 13, 19)
+PARITY_IDX = [r * 21 + c for r in PARITY_GRID for c in PARITY_GRID]
 
 
 def tile_patches(lr_tile):
@@ -44,46 +50,111 @@ def tile_patches(lr_tile):
     return patches * 2.0 - 1.0
 
 
+def hr_patches(hr_tile, idx):
+    """HR counterparts [n, 192, 192, 3] in [0, 1] of the LR patches `idx` of a tile (positions as extract_patches enumerates them)."""
+    out = []
+    for i in idx:
+        r, c = divmod(i, 21)
+        y, x = r * STRIDE * SCALE, c * STRIDE * SCALE
+        out.append(hr_tile[y:y + PATCH * SCALE, x:x + PATCH * SCALE])
+    return np.stack(out)
+
+
+def host_cpu():
+    """(logical CPUs of the node, CPUs this process may run on, model name) -- the north star asks for the core count beside the CPU number."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return os.cpu_count(), usable, model
+
+
 def cpu_baseline(weights, lr_tile, budget_s=20.0, keep=None):
-    """The oracle (CPU restatement, torch-CPU fp32, all host cores) on a bounded sample of the same patches.  `keep`, a dict,
-    receives the oracle's output for the first N_PARITY patches (the parity object compares the GPU with them)."""
+    """The oracle (CPU restatement, torch-CPU fp32) on a bounded sample of the same patches: the PARITY_IDX patches first (their
+    outputs go to `keep`, a dict, for the parity object), then further patches of the tile until the time budget is used."""
     from oracle import models as OM
-    threads = min(os.cpu_count() or 1, 16)     # the GPU box's CPU share for one GPU
+    n_cpu, usable, model = host_cpu()
+    threads = min(usable or 1, 16)     # the GPU box's CPU share for one GPU
     torch.set_num_threads(threads)
     x = tile_patches(lr_tile)
+    order = PARITY_IDX + [i for i in range(len(x)) if i not in set(PARITY_IDX)]
+    outs, n = [], 0
     t0 = time.perf_counter()
-    first = OM.esrgan_g_forward(x[:2], weights, SCALE, NB)
-    per_patch = (time.perf_counter() - t0) / 2
-    if keep is not None:
-        keep["fp32_reference_graph"] = first[:N_PARITY]
-    n = int(min(len(x) - 2, max(2, budget_s / max(per_patch, 1e-3))))
-    t0 = time.perf_counter()
-    for i in range(2, 2 + n, 2):
-        OM.esrgan_g_forward(x[i:i + 2], weights, SCALE, NB)
+    while n < len(order) and (n < len(PARITY_IDX) or time.perf_counter() - t0 < budget_s):
+        outs.append(OM.esrgan_g_forward(x[order[n:n + 2]], weights, SCALE, NB))
+        n += 2
     dt = time.perf_counter() - t0
+    n = min(n, len(order))
+    if keep is not None:
+        keep["fp32_reference_graph"] = np.concatenate(outs)[:len(PARITY_IDX)]
     per_tile = dt / n * len(x)
-    return {"value": (LR * SCALE) ** 2 / 1e6 / per_tile, "unit": "MPix/s", "cores": threads, "kind": "port",
-            "sample": f"{n} of {TILES_PER_GPU * len(x)} LR patches 48x48 (ESRGAN x4 NB=23 G=32 with attention, fp32 torch-CPU oracle), "
-                      f"{dt:.1f} s, extrapolated to a 441-patch tile"}
+    return {"value": (LR * SCALE) ** 2 / 1e6 / per_tile, "unit": "MPix/s", "cores": threads, "cpu_count": n_cpu, "cpu_model": model,
+            "kind": "port",
+            "sample": f"{n} of {TILES_PER_GPU * len(x)} LR patches 48x48 (ESRGAN x4 NB=23 G=32 with attention, fp32 torch-CPU oracle, {threads} threads "
+                      f"on a {n_cpu}-CPU host), {dt:.1f} s, extrapolated to a 441-patch tile"}
 
 
-def parity_object(ctx, model, weights, lr_tile, fp32_ref):
-    """GPU (the bench's bf16 generator) vs the oracle on the first N_PARITY LR patches of tile 0, outside the timed region.
+def parity_object(ctx, model, weights, lr_tile, hr_tile, fp32_ref):
+    """GPU (the bench's bf16 generator) vs the oracle on the PARITY_IDX LR patches of tile 0, outside the timed region.
     Like-for-like = the oracle in its bf16-storage mode (rounds to bf16 where the device stores bf16); the plain fp32 reference
-    graph is reported beside it."""
+    graph is reported beside it.  abs_psnr_delta_vs_hr_db is the north star's figure |PSNR(gpu, HR) - PSNR(oracle, HR)| (<= 0.01 dB),
+    per patch, worst case, against the fp32 reference graph (and against the bf16-storage oracle beside it)."""
     from oracle import models as OM
     from oracle import ops as OO
     from sr355.weights import round_to_bf16
-    x = round_to_bf16(tile_patches(lr_tile)[:N_PARITY].astype(np.float32))
+    x = round_to_bf16(tile_patches(lr_tile)[PARITY_IDX].astype(np.float32))
     got = model.generator.forward(ctx.to_device(x, torch.bfloat16)).float().cpu().numpy()
-    ref = OM.esrgan_g_forward(x, weights, SCALE, NB, bf16_storage=True)
-    p01 = lambda a, b: float(OO.psnr((a + 1) / 2, (b + 1) / 2, dtype=np.float64).min())
-    out = {"psnr_gpu_vs_oracle_db": p01(got, ref), "max_abs": float(np.abs(got - ref).max()),
+    ref = np.concatenate([OM.esrgan_g_forward(x[i:i + 2], weights, SCALE, NB, bf16_storage=True) for i in range(0, len(x), 2)])
+    hr = hr_patches(hr_tile, PARITY_IDX).astype(np.float64)
+    to01 = lambda a: np.clip((a.astype(np.float64) + 1) / 2, 0.0, 1.0)
+    p01 = lambda a, b: OO.psnr(to01(a), to01(b), dtype=np.float64)
+    vs_hr = lambda a: OO.psnr(hr, to01(a), dtype=np.float64)
+    out = {"psnr_gpu_vs_oracle_db": float(p01(got, ref).min()), "max_abs": float(np.abs(got - ref).max()),
            "rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "n_patches": int(len(x)),
+           "patches": "4 x 4 grid over tile 0's 21 x 21 patch positions (rows/cols 0, 6, 13, 19)",
+           "abs_psnr_delta_vs_hr_db_bf16_storage_oracle": float(np.abs(vs_hr(got) - vs_hr(ref)).max()),
            "oracle": "CPU restatement, fp32 arithmetic, bf16 storage where the device stores bf16 (oracle.models bf16_storage=True)"}
     if fp32_ref is not None:
-        out["psnr_gpu_vs_fp32_reference_graph_db"] = p01(got, fp32_ref[:len(x)])
+        out["psnr_gpu_vs_fp32_reference_graph_db"] = float(p01(got, fp32_ref[:len(x)]).min())
+        out["abs_psnr_delta_vs_hr_db"] = float(np.abs(vs_hr(got) - vs_hr(fp32_ref[:len(x)])).max())
+        out["north_star_bar_db"] = 0.01
     return out
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n, argv, port):
+    """The command that runs this file as n ranks of one node (one rank per GPU over RCCL): what the driver's own torchrun line does."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children and relay rank 0's JSON line.  The parent must not
+    hold a GPU context (a process that has initialised the GPU must never be replaced or forked into ranks on this pool): it touches
+    no torch.cuda call before this point, and refuses if something already did."""
+    if torch.cuda.is_initialized():
+        raise RuntimeError("bench.py --gpus N: the launching process already holds a GPU context; start the ranks from a process that has not touched the GPU")
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+    if n > have and not os.environ.get("SR355_ONE_DEVICE"):
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (SR355_ONE_DEVICE=1 rehearses the N-rank plumbing on one GPU over gloo)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(launch_command(n, argv, free_port()), env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:                    # rank 0's line (and nothing else) goes to stdout; the ranks' stderr passes straight through
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def roofline_object(dom, traffic, instrumented_ms_per_step, clock_mhz=None):
@@ -133,6 +204,13 @@ def main():
     args = ap.parse_args()
     if args.chunk <= 0:
         args.chunk = 441 * max(1, args.tiles_per_call)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={env_world}: the two must agree")
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -141,7 +219,9 @@ def main():
         torch.cuda.set_device(0)
     else:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, world, local = D.init_from_env(backend=os.environ.get("SR355_DIST_BACKEND", "nccl"))   # "gloo" only for that rehearsal
+    # RCCL ("nccl") on a real node; gloo only for the one-device rehearsal (RCCL refuses two ranks on one GPU)
+    rank, world, local = D.init_from_env(backend=os.environ.get("SR355_DIST_BACKEND", "gloo" if os.environ.get("SR355_ONE_DEVICE") else "nccl"))
+    group_world = torch.distributed.get_world_size() if world > 1 else 1      # what the process group itself reports
     if os.environ.get("SR355_ONE_DEVICE"):
         local = 0
     scaling = args.scaling or ("strong" if world > 1 else "weak")
@@ -224,11 +304,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # per-step device time beside the contract's wall clock: one event between steps on the launching stream (no host sync inside the
+    # timed region); SURVEY.md 8(d) asks for the median, the driver's contract for K steps / wall time -- `value` is the latter
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     # the same K steps again with a HIP-event pair around every hot-kernel launch (on the launching stream):
     # per-kernel durations for the roofline object.  `value` comes from the un-instrumented pass above.
     prof, elapsed_prof = [], None
@@ -259,7 +346,8 @@ def main():
             roof = roofline_object(dom, traffic, elapsed_prof / args.steps * 1e3, clock_mhz)
         line = {
             "metric": "4x-SR MPix/s on 512x512 LR batch", "value": mpix * args.steps / elapsed, "unit": "MPix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": group_world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median_device": median_ms, "value_at_median_step": mpix / (median_ms * 1e-3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (seeded 3D-print tiles; seeded glorot-uniform weights" + ("" if args.raw_glorot else
                     ", attention logits conditioned by 2^-8: sr355.weights.condition_attention") + ")",
@@ -267,7 +355,9 @@ def main():
                                    "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
                        "tiles_this_rank": n_mine, "global_batch": global_tiles, "patches_per_forward": min(args.chunk, 441 * max(n_mine, 1)),
                        "tiles_per_call": args.tiles_per_call, "fused_dense_pairs_mask": args.fused,
-                       "parallelism": f"dp{world} (tile shards, metric all-reduce only)"},
+                       "distinct_tiles": 4, "tile_of_batch_index": "batch tile t is synthetic tile t % 4 (4 distinct 512x512 tiles, each 4 times; nothing is cached between tiles)",
+                       "world_size_env": world, "world_size_process_group": group_world, "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
+                       "parallelism": f"dp{group_world} (tile shards, metric all-reduce only)"},
             "quality": {"mean_psnr_vs_hr_db": res[0] / res[2], "mean_ssim_vs_hr": res[1] / res[2], "note": "random-init weights"},
             "whole_step": {"conv_tflop": CONV_TFLOP_PER_TILE * global_tiles, "conv_tflops_all_ranks": CONV_TFLOP_PER_TILE * global_tiles / (elapsed / args.steps),
                            "frac_of_bf16_mfma_peak": CONV_TFLOP_PER_TILE * global_tiles / (elapsed / args.steps) / (PEAK_BF16_TFLOPS * world),
@@ -281,7 +371,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, lr4[0], keep=kept)
         if world == 1 and not args.no_parity and not args.no_attention:
-            line["parity"] = parity_object(ctx, model, weights, lr4[0], kept.get("fp32_reference_graph"))
+            line["parity"] = parity_object(ctx, model, weights, lr4[0], hr4[0], kept.get("fp32_reference_graph"))
         print(json.dumps(line), flush=True)
     if world > 1:
         D.shutdown()

@@ -37,3 +37,71 @@ def test_high_intensity_kernel_is_mfma_bound(bench):
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == bench.PEAK_BF16_TFLOPS
     assert r["achieved"] == pytest.approx(r["mfma_tflops"]) and r["frac"] == pytest.approx(r["mfma_frac"])
     assert r["traffic"] is None and r["tighter_roof"] == "mfma" and "peak_at_measured_clock" not in r
+
+
+# ---- `python bench.py --gpus N` outside torchrun starts its own ranks: the parent touches no GPU
+
+def test_launch_command_is_the_drivers_torchrun_line(bench):
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], 12345)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3"]
+
+
+def test_launcher_refuses_when_the_parent_holds_a_gpu_context(bench, monkeypatch):
+    monkeypatch.setattr(bench.torch.cuda, "is_initialized", lambda: True)
+    started = []
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda *a, **k: started.append(a))
+    with pytest.raises(RuntimeError, match="GPU context"):
+        bench.launch_ranks(2, ["--gpus", "2"])
+    assert not started
+
+
+def test_launcher_refuses_more_ranks_than_gpus_unless_rehearsing(bench, monkeypatch):
+    monkeypatch.setattr(bench.torch.cuda, "is_initialized", lambda: False)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("SR355_ONE_DEVICE", raising=False)
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.launch_ranks(2, ["--gpus", "2"])
+
+
+def test_main_self_launches_for_gpus_gt_1_without_torchrun_env_and_relays_the_exit_code(bench, monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1"])
+    seen = {}
+
+    def fake_launch(n, argv):
+        seen["n"], seen["argv"] = n, list(argv)
+        return 7
+    monkeypatch.setattr(bench, "launch_ranks", fake_launch)
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("the parent must not touch the GPU")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "1"]}
+
+
+def test_main_rejects_a_world_size_that_disagrees_with_gpus(bench, monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.main()
+
+
+def test_launcher_relays_rank0_stdout_and_exit_code(bench, monkeypatch, capsys):
+    """End to end on the CPU: the launcher's Popen/relay loop with a stand-in child command."""
+    monkeypatch.setattr(bench.torch.cuda, "is_initialized", lambda: False)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(bench, "launch_command", lambda n, argv, port: [bench.sys.executable, "-c", "import sys; print('{\"n_gpus\": 2}'); sys.exit(3)"])
+    rc = bench.launch_ranks(2, ["--gpus", "2"])
+    assert rc == 3 and capsys.readouterr().out.strip() == '{"n_gpus": 2}'
+
+
+def test_parity_patches_cover_the_tile_and_have_hr_counterparts(bench):
+    import numpy as np
+    assert len(bench.PARITY_IDX) == 16 and len(set(bench.PARITY_IDX)) == 16 and max(bench.PARITY_IDX) < 441
+    hr = np.arange(2048 * 2048 * 3, dtype=np.float32).reshape(2048, 2048, 3)
+    hp = bench.hr_patches(hr, bench.PARITY_IDX)
+    assert hp.shape == (16, 192, 192, 3)
+    r, c = divmod(bench.PARITY_IDX[5], 21)
+    assert hp[5, 0, 0, 0] == hr[r * 96, c * 96, 0] and r * 96 + 192 <= 2048 and c * 96 + 192 <= 2048
