@@ -85,11 +85,18 @@ int  sr_measure_clock(sr_ctx* ctx, float* mhz, void* stream);
  * [{"kernel","launches","total_ms","flops","bytes"}...] (algorithmic FLOP / HBM bytes per kernel
  * template instance) into `json` (capacity `cap` bytes). */
 /* Diagnostic only (never set in production): a device buffer of 16 uint64 per workgroup of the next 3x3 bf16 conv
- * launches; a separately compiled stamped variant of the kernel writes s_memtime stamps there (NULL switches back). */
-int  sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer);
+ * launches; a separately compiled stamped variant of the kernel writes s_memtime stamps there (NULL switches back).
+ * `capacity_bytes` is the size of that buffer: a launch whose grid would write beyond it is refused with SR_ERR_INVALID
+ * instead of running (round 2's one memory fault was a probe handing a buffer sized for another kernel).
+ * sr_debug_stamp_bytes_needed(0, workgroups) is the size a launch of `workgroups` workgroups needs. */
+int  sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer, int64_t capacity_bytes);
 /* Diagnostic only: a device buffer of 64 x 4 x 64 x 4 uint64 for the stamped variant of the fused dense-block kernels (s_memtime at four
- * points of each of the first 64 granules, waves 0, 5, 8, 11 of the first 64 workgroups; tools/probe_chain.py).  NULL switches back. */
-int  sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer);
+ * points of each of the first 64 granules, waves 0, 5, 8, 11 of the first 64 workgroups; tools/probe_chain.py).  NULL switches back.
+ * A non-NULL buffer smaller than sr_debug_stamp_bytes_needed(1, 0) is refused with SR_ERR_INVALID. */
+int  sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer, int64_t capacity_bytes);
+/* Bytes of stamp buffer the stamped diagnostic kernels write: which = 0 -> the 3x3 conv (16 uint64 per workgroup of the launch),
+ * which = 1 -> the fused dense-block kernels (fixed size; `workgroups` ignored).  Pure function, no context; -1 for anything else. */
+int64_t sr_debug_stamp_bytes_needed(int which, int64_t workgroups);
 /* Which dense-block conv pairs of the ESRGAN trunk run as one fused line-buffer kernel when the shape allows (bf16, 32 growth
  * channels, 48-pixel-wide images): bit 0 = conv4+conv5, bit 1 = conv2+conv3; default 3.  mask 0 = layer by layer (the A/B switch of
  * the parity tests and of tools/ benchmarks).  max_workgroups > 0 caps the persistent grid (tests: several images per workgroup

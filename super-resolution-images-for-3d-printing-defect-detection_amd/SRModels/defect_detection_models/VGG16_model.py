@@ -34,7 +34,14 @@ class FineTunedVGG16(DeviceModelMixin):
         weights = load_pretrained(pretrained_path) if from_pretrained else None
         if weights is not None:
             num_classes = int(weights["predictions"][0].shape[-1])
-        self.base_trainable, self.dropout_rate, self.l2_reg, self.learning_rate = bool(base_trainable), float(dropout_rate), float(l2_reg), float(learning_rate)
+        # base_trainable / train_last_n_layers (VGG16_model.py:75-82): the reference sets `base.trainable = False` on the nested VGG16
+        # model and then `layer.trainable = True` on its last n sub-layers.  In Keras a frozen parent model keeps its sub-layers' weights
+        # out of trainable_weights whatever their own flag says, and the base is called with training=False: the base STAYS FROZEN, and
+        # the notebook that passes (train_last_n_layers=6, base_trainable=True) reports 131 842 trainable parameters = the two Dense
+        # layers (VGG16.ipynb:L152,L161-165).  So both arguments are accepted and recorded, and training is the
+        # same head-only training in either case -- the reference's behaviour, not its apparent intent.
+        self.base_trainable, self.train_last_n_layers = bool(base_trainable), int(train_last_n_layers)
+        self.dropout_rate, self.l2_reg, self.learning_rate = float(dropout_rate), float(l2_reg), float(learning_rate)
         if loss != "sparse_categorical_crossentropy":
             raise ValueError("only sparse_categorical_crossentropy (the reference's default, VGG16_model.py:29) is built")
         self._make("vgg16", self.compute_dtype, num_classes=num_classes)
@@ -43,6 +50,16 @@ class FineTunedVGG16(DeviceModelMixin):
             print(f"Loaded pretrained model from {pretrained_path}")
         else:
             self._random_init(seed=4000)
+
+    def trainable_layers(self):
+        """Layers whose parameters `fit` updates: the two Dense layers, with or without base_trainable (see setup_model)."""
+        return ["dense", "predictions"]
+
+    def count_params(self, trainable_only=False):
+        """Keras `model.count_params()` / the "Trainable params" line of model.summary(): 14 846 530 / 131 842 at num_classes=2
+        (VGG16.ipynb:L151-153)."""
+        names = self.trainable_layers() if trainable_only else list(self.weights)
+        return int(sum(np.asarray(k).size + np.asarray(b).size for k, b in (self.weights[n] for n in names)))
 
     # ------------------------------------------------------------------ training of the head on the frozen base (VGG16_model.py:111-166)
     def _gap_features(self, images, batch_size=256):
@@ -79,14 +96,13 @@ class FineTunedVGG16(DeviceModelMixin):
         return out
 
     def fit(self, X_train, y_train, X_val, y_val, batch_size=32, epochs=50, use_augmentation=True, seed=42):
-        """FineTunedVGG16.fit (VGG16_model.py:111-157) for the default frozen base: the conv base runs on the device per batch, the
-        two Dense layers train on the host (Adam, sparse CCE, Dropout, EarlyStopping / ReduceLROnPlateau).  With augmentation the
-        batches are 32 images, as the reference's datagen.flow(..., batch_size=32) hard-codes."""
+        """FineTunedVGG16.fit (VGG16_model.py:111-157): the conv base runs on the device per batch, the two Dense layers train on the
+        host (Adam, sparse CCE, Dropout, EarlyStopping / ReduceLROnPlateau).  The base is frozen with and without base_trainable,
+        as in the reference (setup_model).  With augmentation the batches are 32 images, as the reference's
+        datagen.flow(..., batch_size=32) hard-codes."""
         from sr355.train import fit_head
         if self.model is None:
             raise ValueError("Model is not built yet.")
-        if self.base_trainable:
-            raise NotImplementedError("fine-tuning the VGG16 conv layers (base_trainable=True) is not built; the default frozen base is")
         X_train, y_train = np.asarray(X_train, np.float32), np.asarray(y_train, np.int64).reshape(-1)
         rng = np.random.default_rng(seed)
         bs = 32 if use_augmentation else int(batch_size)

@@ -44,11 +44,16 @@ void sr_ctx::dfree(void* p) {
     if (it != allocs.end()) { cur_bytes -= (int64_t)it->second; allocs.erase(it); }
     (void)hipFree(p);
 }
+// hipFuncAttributeMaxDynamicSharedMemorySize of `kernel` covers at least `bytes`.  The largest size set so far is remembered per kernel:
+// kernels whose LDS grows with the image (the spectral-loss kernels: 56 / 80 bytes per pixel of width) raise it again when a wider
+// image arrives (the first size used to be pinned and a later, wider launch failed with an opaque HIP error).
 int sr_ctx::ensure_dyn_lds(const void* kernel, int bytes) {
-    if (lds_attr_done.count(kernel)) return SR_OK;
+    if (bytes > MAX_LDS_BYTES) return fail(SR_ERR_INVALID, "kernel needs " + std::to_string(bytes) + " bytes of LDS, a CU has " + std::to_string(MAX_LDS_BYTES));
+    auto it = lds_attr_done.find(kernel);
+    if (it != lds_attr_done.end() && it->second >= bytes) return SR_OK;
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return fail(SR_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-    lds_attr_done.insert(kernel);
+    lds_attr_done[kernel] = bytes;
     return SR_OK;
 }
 void* sr_ctx::scratch(size_t bytes) {
@@ -486,9 +491,18 @@ int sr_last_forward_ms(sr_ctx* ctx, float* ms) {
     return SR_OK;
 }
 
-int sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer) {
+int64_t sr_debug_stamp_bytes_needed(int which, int64_t workgroups) {
+    if (which == 0) return workgroups < 0 ? -1 : workgroups * 16 * (int64_t)sizeof(unsigned long long);
+    if (which == 1) return (int64_t)64 * 4 * 64 * 4 * (int64_t)sizeof(unsigned long long);
+    return -1;
+}
+
+int sr_debug_set_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer, int64_t capacity_bytes) {
     if (!ctx) return SR_ERR_INVALID;
+    if (device_u64_buffer && capacity_bytes < sr_debug_stamp_bytes_needed(0, 1))
+        return ctx->fail(SR_ERR_INVALID, "sr_debug_set_stamp_buffer: the buffer does not hold one workgroup's stamps");
     ctx->stamp_buf = static_cast<unsigned long long*>(device_u64_buffer);
+    ctx->stamp_cap = device_u64_buffer ? capacity_bytes : 0;
     return SR_OK;
 }
 
@@ -498,8 +512,10 @@ int sr_measure_clock(sr_ctx* ctx, float* mhz, void* stream) {
     return clock_probe_launch(ctx, mhz, static_cast<hipStream_t>(stream));
 }
 
-int sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer) {
+int sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer, int64_t capacity_bytes) {
     if (!ctx) return SR_ERR_INVALID;
+    if (device_u64_buffer && capacity_bytes < sr_debug_stamp_bytes_needed(1, 0))
+        return ctx->fail(SR_ERR_INVALID, "sr_debug_set_chain_stamp_buffer: the buffer is smaller than the stamped kernels write (sr_debug_stamp_bytes_needed(1, 0))");
     ctx->chain_stamp_buf = static_cast<unsigned long long*>(device_u64_buffer);
     const char* skip = getenv("SR355_CHAIN_STAMP_SKIP");
     ctx->chain_stamp_skip = skip ? atoi(skip) : -1;

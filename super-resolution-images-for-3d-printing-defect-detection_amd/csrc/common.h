@@ -29,6 +29,7 @@ struct sr_ctx {
     void* scratch_buf = nullptr;
     size_t scratch_cap = 0;
     unsigned long long* stamp_buf = nullptr;   // diagnostic: when set, conv3_rows runs its stamped variant
+    int64_t stamp_cap = 0;                     // ... bytes behind stamp_buf: a launch that would write beyond is refused
     int chain_stamp_skip = -1;                        // diagnostic: >= 0 -> only the launch after that many fused launches is stamped (env SR355_CHAIN_STAMP_SKIP)
     unsigned long long* chain_stamp_buf = nullptr;   // diagnostic: when set, the fused dense-block kernels run their stamped variant
 
@@ -43,13 +44,14 @@ struct sr_ctx {
     void prof_close(int rec, hipStream_t st);
 
     // kernels whose dynamic-LDS ceiling has been raised on THIS context's device (hipFuncSetAttribute is per device)
-    std::unordered_set<const void*> lds_attr_done;
+    static constexpr int MAX_LDS_BYTES = 160 * 1024;          // LDS of one gfx950 CU
+    std::unordered_map<const void*, int> lds_attr_done;      // kernel -> largest dynamic-LDS size its attribute has been raised to
     int ensure_dyn_lds(const void* kernel, int bytes);
     void* tab_buf = nullptr; size_t tab_cap = 0;   // tap tables of sr_resize (stream-ordered reuse)
     struct Arena { void* p = nullptr; size_t cap = 0; };
     Arena dev_w, dev_b, dev_x;    // sr_conv2d_dev: packed weights / padded bias / padded input of the call in flight (stream-ordered reuse)
     void* arena(Arena& a, size_t bytes, hipStream_t st);   // grow-only; growing waits for `st` first
-    void* zero_page = nullptr;    // 4 KiB of zeros (DMA source of padding rows in dense_fused.hip)
+    void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int chain_mask = 3;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3 (sr_debug_set_fused; default both)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup

@@ -280,7 +280,9 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     if (nwg >= (1ll << 31)) return ctx->fail(SR_ERR_INVALID, "conv_rows: too many workgroups for one launch");
     p.tilesX = (nct << 16) | tilesX;
     dim3 grid((unsigned)nwg, 1u);
-    if (p.dbg) {   // diagnostic stamped variant
+    if (p.dbg) {   // diagnostic stamped variant: 16 stamps per workgroup, refused when the buffer is too small for this grid
+        if (nwg * 16 * (int64_t)sizeof(unsigned long long) > ctx->stamp_cap)
+            return ctx->fail(SR_ERR_INVALID, "conv_rows: the stamp buffer is too small for this launch (sr_debug_stamp_bytes_needed(0, workgroups))");
         auto kd = conv3_rows_kernel<NB16, R, true>;
         if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kd), lds)) return rc;
         hipLaunchKernelGGL(kd, grid, dim3(256), lds, st, p);

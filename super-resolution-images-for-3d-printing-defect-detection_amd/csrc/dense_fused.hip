@@ -44,7 +44,7 @@ struct ChainParams {
     const char* so; int so_nch;        // MODE 1: the other skip tensor (64 channels at chunk 0 of a row-blocked buffer) or nullptr
     const char* w;                     // granule-ordered packed weights (pack_chain_weights)
     const float* bias;                 // [16*NB0 | 16*NB1] fp32
-    const char* zero;                  // >= 1 KiB of zeros: DMA source of separator / out-of-stream rows
+    const char* zero;                  // ZERO_PAGE_BYTES of zeros: DMA source of separator / out-of-stream rows (same chunk offsets as real rows)
     int B, H;
     int imgs_per_wg; unsigned magic;   // g / (H+1) == umulhi(g, magic) for every stream row index that occurs
     float alpha, xscale, beta_o;       // MODE 1: out = alpha * (acc + bias + xscale * x) + beta_o * so
@@ -58,6 +58,7 @@ constexpr int ROWB = 3072;             // one LDS / HBM row of a chunk: 48 pixel
 constexpr int NSTG = 11;               // staged rows per chunk: stream rows [8s-2, 8s+9)
 constexpr int STGB = NSTG * ROWB;
 constexpr int WINR = 10;               // ring rows of layer 0's output: [8s-2, 8s+8)
+constexpr int ZERO_PAGE_BYTES = 32768;
 
 template <int NB0, int NB1, int MODE> struct ChainLds {
     static constexpr int WSLOT = (NB0 + NB1) * 3 * 1024;
@@ -84,6 +85,35 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
         f(std::integral_constant<int, N - 1>{});
     }
 }
+
+// s_waitcnt vmcnt(N) with a compile-time N: everything but this wave's N youngest vector-memory operations has completed
+template <int N> __device__ __forceinline__ void wait_imm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// What loader wave LW issues where, as compile-time functions of the granule position in a step (chain2_kernel's loader section).
+template <int EXT, int NB0, int NB1, int MODE, int LW> struct LoaderPlan {
+    static constexpr int NBT = NB0 + NB1, EXTG = 3 * EXT, NGR = 3 * (EXT + 1);
+    static constexpr int RT_E = MODE == 1 ? 2 : 3;      // resident pieces per loader of an external granule's ceil(3 NBT / 4) = 5 (tail) / 3 (growth pair)
+    static constexpr int RT_R = 2;                      // ... of a ring granule's ceil(3 NB1 / 4) = 3 / 2
+    // rows of a chunk requested in the chunk's granule kx: {LW, LW + 4} | {8 + LW} (LW < 3) | {}
+    static constexpr int nrows(int kx) { return kx == 0 ? 2 : kx == 1 ? (LW < 3 ? 1 : 0) : 0; }
+    // row pieces requested at granule position i of a step (any integer: the pattern repeats every step)
+    static constexpr int nst_at(int i) {
+        i = (i % NGR + NGR) % NGR;
+        return i < EXTG ? 3 * nrows(i % 3) : 0;
+    }
+    // weight pieces fetched by DMA (the non-resident ones) for the granule at position iw
+    static constexpr int nwdma(int iw) {
+        const bool ext = iw < EXTG;
+        const int nw = ext ? NBT * 3 : NB1 * 3, rt = ext ? RT_E : RT_R;
+        int n = 0;
+        for (int t = 0; t < (nw + 3) / 4; ++t)
+            if (LW + 4 * t < nw && t >= rt) ++n;
+        return n;
+    }
+};
 
 constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + loader waves (LDS-DMA issue only), one loader per SIMD
 
@@ -140,162 +170,165 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     auto dma = [&](const char* src, char* dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    // nt (aux = 2): a line fetched with it is not kept in L2.  Used for the rows of a step that no later step reads again, so that the
-    // three halo rows the NEXT step re-reads (11 staged rows, 8 new) are what survives in the XCD's 4 MiB between two steps.
-    auto dma_nt = [&](const char* src, char* dst) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
-    };
-    auto wait_all_but = [&](int n) {          // s_waitcnt vmcnt(n): everything but this wave's n youngest vector-memory operations has completed
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-            case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-            case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
-            case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-            case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-            case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
-            case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-            case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
-            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than the table covers: wait for everything (slower, never wrong)
-        }
-    };
-
     if (wave >= NCOMP) {
         // =========================================================================================== loader waves
-        const int lw = wave - NCOMP;
+        // Round 3.  tools/micro/port_probe.hip (profiles/r03_port_probe.txt) measured what the CU's vector-memory path delivers into LDS
+        // when the issuing loop is nothing but the DMA instructions: 59 B/clk from L2 (17 cycles per 1 KiB piece) with four loader
+        // waves, 12 B/clk per CU from HBM with every CU streaming (the chip's 7 TB/s) and 25 B/clk with eight CUs -- beside eight MFMA
+        // waves just the same.  Round 2's loaders spent ~200-250 cycles of SCALAR work per piece (row -> image by umulhi, 64-bit
+        // multiplies, zero-page select, branches: ~45 instructions) and that, not the port, was the 54 k cycles per step the stamps
+        // showed with the MFMA bodies skipped.  So: everything about a piece that does not change is computed once.
+        //   * a loader owns whole rows of a staged chunk (three consecutive 1 KiB pieces: ONE address, immediate offsets 0 / 1024 / 2048
+        //     on both the global and the LDS side) -- rows LW and LW + 4 in a chunk's first granule, row 8 + LW in its second, none in its
+        //     third, so that no row is requested in the iteration whose barrier publishes it;
+        //   * the base address of a row (image, row, separator or out of stream -> zero page) is computed once per STEP and row, in scalar
+        //     registers, and serves every chunk of the step; the zero page is large enough to take the same chunk offset;
+        //   * the loader's number is a compile-time constant (four copies of the code): piece lists, resident-weight indices and every
+        //     s_waitcnt count are immediates; out-of-stream rows and the weights "after the last step" are issued all the same
+        //     (zero page / valid memory, nobody reads them), so the counts never depend on the position in the stream.
+        const int lwr = wave - NCOMP;
         // LDS-DMA source swizzle: lane i of a 1 KiB piece fills LDS slot i -> pixel i/4, slice position i%4, which must hold global slice
         // (i%4) ^ 2*bit2(pixel)
         const int lsrc = 64 * (lane >> 2) + 16 * ((lane & 3) ^ (2 * ((lane >> 4) & 1)));
-        auto stage_piece = [&](int s2, int c1, int pid, char* sdst) {   // piece pid (row j, 16-pixel third pc) of chunk c1 of step s2
-            const int j = pid / 3, pc = pid - 3 * j;
-            int img, y;
-            const bool real = row_of(8 * s2 - 2 + j, img, y);
-            const char* src = real ? p.in + (((int64_t)(img0 + img) * H + y) * p.in_nch + c1) * ROWB + pc * 1024 + lsrc : p.zero + lane * 16;
-            if (j < 8) dma_nt(src, sdst + j * ROWB + pc * 1024);
-            else dma(src, sdst + j * ROWB + pc * 1024);
-        };
-        // Schedule.  In the iteration of granule g (after the barrier that opens g) a loader issues
-        //   * the weights of granule g+2 into ring slot (g+2) % 3 (last read in granule g-1), and
-        //   * in each of the three granules of an external chunk n, a third of chunk n+1's 33 row pieces into staging buffer (n+1) & 1
-        //     (last read in chunk n-1) -- an even 29 pieces per iteration; 35 / 34 / 18 left the compute waves waiting ~1.4 k cycles for
-        //     the loaders in two granules of three and the loaders for the compute waves in the third,
-        // then waits, with a COUNTED vmcnt, for what it issued in the PREVIOUS iteration (vmcnt retires in order) and meets the
-        // barrier that opens granule g+1 -- which therefore publishes granule g+1's weights and, after the second granule of chunk n,
-        // all of chunk n+1.  Every piece has a full granule of MFMA time to land; the loaders' own limit is the CU's vector-memory
-        // issue port (~40-50 cycles per 1 KiB piece, in-kernel stamps).
-        // Resident weights.  The path from L2 into a CU moves ~16 B/clk whatever issues the loads (stamps: loaders alone, compute
-        // bodies skipped, take the same ~65 cycles per 1 KiB piece; 8 or 252 workgroups on the chip make no difference), and
-        // every 8-row step re-reads ALL weights: 54 of a tail chunk's 87 pieces.  A loader wave needs ~30 registers and owns 168, so
-        // each keeps the first RT_E (RT_R) of its pieces of every external (ring) granule in registers for the whole kernel -- 132 KiB
-        // of the tail's 306 KiB, all of a growth pair's 90 / 126 KiB -- and writes them into the weight slot with ds_write_b128 (the
-        // LDS write path, not the memory port) where the DMA version issued a load.
-        constexpr int RT_E = MODE == 1 ? 2 : 3;                          // of ceil(3 NBT / 4) = 5 (tail) / 3 (growth pair) pieces per loader and granule
-        constexpr int RT_R = 2;                          // of ceil(3 NB1 / 4) = 3 / 2
-        u32x4 wre[EXTG][RT_E], wrr[3][RT_R];
-        auto wsrc_of = [&](int iw) { return p.w + (iw < EXTG ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024)); };
-#pragma unroll
-        for (int iw = 0; iw < EXTG; ++iw)
-#pragma unroll
-            for (int t = 0; t < RT_E; ++t)
-                if (lw + 4 * t < NBT * 3) wre[iw][t] = *reinterpret_cast<const u32x4*>(wsrc_of(iw) + (lw + 4 * t) * 1024 + lane * 16);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int t = 0; t < RT_R; ++t)
-                if (lw + 4 * t < NB1 * 3) wrr[r][t] = *reinterpret_cast<const u32x4*>(wsrc_of(EXTG + r) + (lw + 4 * t) * 1024 + lane * 16);
-        // weights of the granule at position IW of a step (running number Gw) -> slot Gw % NWS; returns the DMA pieces issued
-        auto put_weights = [&](auto IW, int Gw, bool live) -> int {
-            constexpr int iw = decltype(IW)::value;
-            constexpr bool ext = iw < EXTG;
-            constexpr int nw = ext ? NBT * 3 : NB1 * 3, rt = ext ? RT_E : RT_R;
-            if (!live) return 0;
-            const char* wq = p.w;
-            asm volatile("" : "+s"(wq));                                 // recompute the piece addresses here: hoisted out of the step loop they cost two registers each
-            const char* wsrc = wq + (ext ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024));
-            char* wdst = wr + (Gw % NWS) * WSLOT;
-            int n = 0;
-#pragma unroll
-            for (int t = 0; t < (nw + 3) / 4; ++t) {
-                const int k = lw + 4 * t;
-                if (k < nw) {
-                    if (t < rt) {
-                        if constexpr (ext) *reinterpret_cast<u32x4*>(wdst + k * 1024 + lane * 16) = wre[ext ? iw : 0][t < RT_E ? t : 0];
-                        else *reinterpret_cast<u32x4*>(wdst + k * 1024 + lane * 16) = wrr[ext ? 0 : iw - EXTG][t < RT_R ? t : 0];
-                    } else {
-                        dma(wsrc + k * 1024 + lane * 16, wdst + k * 1024);
-                        ++n;
-                    }
-                }
-            }
-            return n;
-        };
-        // prologue: weights of the first WL granules, the first SL external chunks of step 0; all of it is waited for before the first barrier
-        constexpr int WL = NWS - 1;                                      // weights run WL granules ahead
-        constexpr int SL = NSB - 1;                                      // rows run SL chunks ahead
-        static_assert(MODE == 1 || (RT_E * NLOAD >= NBT * 3 && RT_R * NLOAD >= NB1 * 3), "growth pairs: every weight piece is resident (no weight DMA in the counted waits)");
-        static_for<WL>([&](auto I) { put_weights(I, decltype(I)::value, true); });
-        for (int c0 = 0; c0 < SL; ++c0)
-            for (int k = lw; k < 33; k += NLOAD) stage_piece(0, c0, k, stg + c0 * STGB);
-        int nch = 0, prev_stage = 0, prev_stage2 = 0;
-        for (int s = 0; s < nsteps; ++s) {
-            static_for<NGR>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                CHAIN_STAMP(0);
-                // retire the previous iteration's pieces (all but the ones this iteration will issue are older) -- first iteration: everything
-                if (G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the resident pieces written in the previous iteration
-                __builtin_amdgcn_s_barrier();
-                CHAIN_STAMP(1);
-                constexpr int i2 = (i + WL) % NGR;                       // granule G+WL
-                const bool wlive = i + WL < NGR || s + 1 < nsteps;
-                constexpr int kxi = i < EXTG ? i % 3 : -1;
-                // vmcnt retires in order, so the order of issue decides what the counted wait can leave in flight.  Tail: the next barrier
-                // must publish the weights of granule G+1 (issued FIRST in the previous iteration) and, after the third granule of a chunk,
-                // all of the next chunk's rows.  Granules 0 / 1 of a chunk: weights, then rows; wait for all but (the previous iteration's
-                // rows + everything of this one).  Granule 2: rows first, then weights; wait for all but these weights.  Growth pairs: no
-                // weight DMA; the rows needed next were issued at least three iterations ago: wait for all but the last three iterations'.
-                int nw_dma = 0, nst = 0;
-                if (kxi != 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + WL, wlive);
-                if constexpr (i < EXTG) {
-                    constexpr int c = i / 3, kx = i - 3 * c;
-                    int c1 = c + SL, s2 = s;
-                    if (c1 >= EXT) { c1 -= EXT; s2 = s + 1; }
-                    if (s2 < nsteps) {
-                        char* sdst = stg + ((nch + SL) % NSB) * STGB;
-                        for (int k = 11 * kx + lw; k < 11 * kx + 11; k += NLOAD, ++nst) stage_piece(s2, c1, k, sdst);
-                    }
-                    if (kx == 2) ++nch;
-                }
-                if (kxi == 2) nw_dma = put_weights(std::integral_constant<int, i2>{}, G + WL, wlive);
-                CHAIN_STAMP(2);
-                if (MODE == 0) {
-                    wait_all_but(nst + prev_stage + prev_stage2);
-                    prev_stage2 = prev_stage; prev_stage = nst;
+        auto loader = [&](auto LWc) {
+            constexpr int LW = decltype(LWc)::value;
+            // base address of staged row j of step s2 (stream row 8 s2 - 2 + j), chunk 0, this lane's slice
+            auto row_base = [&](int s2, int j) -> const char* {
+                int img, y;
+                const bool real = row_of(8 * s2 - 2 + j, img, y);
+                return real ? p.in + ((int64_t)(img0 + img) * H + y) * p.in_nch * ROWB : p.zero;
+            };
+            // rows of a chunk this loader requests in the chunk's granule kx: {LW, LW + 4} | {8 + LW} (LW < 3) | {}
+            using Plan = LoaderPlan<EXT, NB0, NB1, MODE, LW>;
+            const char* rb_cur[3];
+            const char* rb_nxt[3];
+            auto bases_of = [&](int s2, const char* (&rb)[3]) {
+                rb[0] = row_base(s2, LW);
+                rb[1] = row_base(s2, LW + 4);
+                rb[2] = row_base(s2, 8 + (LW < 3 ? LW : 2));
+            };
+            // one staged row = three pieces; rows 0..7 of a step are read by no later step (nt), rows 8..10 are the next step's halo
+            auto stage_row = [&](auto Jc, const char* rb, int c1, char* sdst) {
+                constexpr int j = decltype(Jc)::value;
+                const char* src = rb + c1 * ROWB + lsrc;
+                char* dst = sdst + j * ROWB;
+                const auto gs = (const __attribute__((address_space(1))) void*)src;
+                const auto ld = (__attribute__((address_space(3))) void*)dst;
+                if constexpr (j < 8) {
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 2);
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 2);
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 2);
                 } else {
-                    wait_all_but(kxi == 2 ? nw_dma : nw_dma + nst + prev_stage);
-                    prev_stage = kxi == 2 ? 0 : nst;
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
                 }
-                CHAIN_STAMP(3);
-                ++G;
+            };
+            auto stage_rows = [&](auto KXc, const char* (&rb)[3], int c1, char* sdst) {
+                constexpr int kx = decltype(KXc)::value;
+                if constexpr (kx == 0) {
+                    stage_row(std::integral_constant<int, LW>{}, rb[0], c1, sdst);
+                    stage_row(std::integral_constant<int, LW + 4>{}, rb[1], c1, sdst);
+                } else if constexpr (kx == 1 && LW < 3) {
+                    stage_row(std::integral_constant<int, 8 + (LW < 3 ? LW : 0)>{}, rb[2], c1, sdst);
+                }
+            };
+            // Resident weights.  Every 8-row step re-reads ALL weights: 54 of a tail chunk's 87 pieces.  A loader wave needs few registers
+            // and owns 168, so each keeps the first RT_E (RT_R) of its pieces of every external (ring) granule in registers for the whole
+            // kernel -- 132 KiB of the tail's 306 KiB, all of a growth pair's 90 / 126 KiB -- and writes them into the weight slot with
+            // ds_write_b128 (the LDS write path, not the memory port) where the DMA version issues a load.
+            constexpr int RT_E = Plan::RT_E, RT_R = Plan::RT_R;
+            u32x4 wre[EXTG][RT_E], wrr[3][RT_R];
+            auto wsrc_of = [&](int iw) { return p.w + (iw < EXTG ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024)); };
+#pragma unroll
+            for (int iw = 0; iw < EXTG; ++iw)
+#pragma unroll
+                for (int t = 0; t < RT_E; ++t)
+                    if (LW + 4 * t < NBT * 3) wre[iw][t] = *reinterpret_cast<const u32x4*>(wsrc_of(iw) + (LW + 4 * t) * 1024 + lane * 16);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < RT_R; ++t)
+                    if (LW + 4 * t < NB1 * 3) wrr[r][t] = *reinterpret_cast<const u32x4*>(wsrc_of(EXTG + r) + (LW + 4 * t) * 1024 + lane * 16);
+            // weights of the granule at position IW of a step (running number Gw) -> slot Gw % NWS
+            auto put_weights = [&](auto IW, int Gw) {
+                constexpr int iw = decltype(IW)::value;
+                constexpr bool ext = iw < EXTG;
+                constexpr int nw = ext ? NBT * 3 : NB1 * 3, rt = ext ? RT_E : RT_R;
+                const char* wq = p.w;
+                asm volatile("" : "+s"(wq));                                 // recompute the piece addresses here: hoisted out of the step loop they cost two registers each
+                const char* wsrc = wq + (ext ? iw * WSLOT : EXTG * WSLOT + (iw - EXTG) * (NB1 * 3 * 1024)) + lane * 16;
+                char* wdst = wr + (Gw % NWS) * WSLOT;
+#pragma unroll
+                for (int t = 0; t < (nw + 3) / 4; ++t) {
+                    const int k = LW + 4 * t;
+                    if (k < nw) {
+                        if (t < rt) {
+                            if constexpr (ext) *reinterpret_cast<u32x4*>(wdst + k * 1024 + lane * 16) = wre[ext ? iw : 0][t < RT_E ? t : 0];
+                            else *reinterpret_cast<u32x4*>(wdst + k * 1024 + lane * 16) = wrr[ext ? 0 : iw - EXTG][t < RT_R ? t : 0];
+                        } else {
+                            dma(wsrc + k * 1024, wdst + k * 1024);
+                        }
+                    }
+                }
+            };
+            // prologue: weights of the first WL granules, the first SL external chunks of step 0; all of it is waited for before the first barrier
+            constexpr int WL = NWS - 1;                                      // weights run WL granules ahead
+            constexpr int SL = NSB - 1;                                      // rows run SL chunks ahead
+            static_assert(MODE == 1 || (RT_E * NLOAD >= NBT * 3 && RT_R * NLOAD >= NB1 * 3), "growth pairs: every weight piece is resident (no weight DMA in the counted waits)");
+            static_assert(SL <= EXT, "rows run at most one step ahead");
+            static_for<WL>([&](auto I) { put_weights(I, decltype(I)::value); });
+            bases_of(0, rb_cur);
+            bases_of(1, rb_nxt);
+            static_for<SL>([&](auto C0) {
+                constexpr int c0 = decltype(C0)::value;
+                stage_rows(std::integral_constant<int, 0>{}, rb_cur, c0, stg + c0 * STGB);
+                stage_rows(std::integral_constant<int, 1>{}, rb_cur, c0, stg + c0 * STGB);
             });
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int nch = 0;
+            for (int s = 0; s < nsteps; ++s) {
+                static_for<NGR>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    CHAIN_STAMP(0);
+                    // first iteration: the prologue has landed
+                    if (G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the resident pieces written in the previous iteration
+                    __builtin_amdgcn_s_barrier();
+                    CHAIN_STAMP(1);
+                    constexpr int i2 = (i + WL) % NGR;                       // granule G+WL
+                    // Order of issue: weights of granule G+WL, then this granule's rows.  vmcnt retires in order.  The barrier that ends this
+                    // iteration publishes the weights of granule G+1 (issued first in the PREVIOUS iteration) and, after a chunk's third granule,
+                    // all of the next chunk's rows (issued in its first two).  Tail: leave in flight this iteration's pieces and -- except in a
+                    // third granule -- the previous iteration's rows (younger than its weights).  Growth pairs (no weight DMA, rows two
+                    // chunks ahead): everything older than three iterations has landed.
+                    put_weights(std::integral_constant<int, i2>{}, G + WL);
+                    if constexpr (i < EXTG) {
+                        constexpr int c = i / 3, kx = i - 3 * c;
+                        constexpr int c1 = (c + SL) % EXT;
+                        constexpr bool next_step = c + SL >= EXT;
+                        char* sdst = stg + ((nch + SL) % NSB) * STGB;
+                        stage_rows(std::integral_constant<int, kx>{}, next_step ? rb_nxt : rb_cur, c1, sdst);
+                        if (kx == 2) ++nch;
+                    }
+                    CHAIN_STAMP(2);
+                    if constexpr (MODE == 0) {
+                        wait_imm<Plan::nst_at(i) + Plan::nst_at(i - 1) + Plan::nst_at(i - 2)>();
+                    } else {
+                        constexpr bool third = i < EXTG && i % 3 == 2;
+                        wait_imm<Plan::nwdma(i2) + Plan::nst_at(i) + (third ? 0 : Plan::nst_at(i - 1))>();
+                    }
+                    CHAIN_STAMP(3);
+                    ++G;
+                });
+                rb_cur[0] = rb_nxt[0]; rb_cur[1] = rb_nxt[1]; rb_cur[2] = rb_nxt[2];
+                bases_of(s + 2, rb_nxt);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        if (lwr == 0) loader(std::integral_constant<int, 0>{});
+        else if (lwr == 1) loader(std::integral_constant<int, 1>{});
+        else if (lwr == 2) loader(std::integral_constant<int, 2>{});
+        else loader(std::integral_constant<int, 3>{});
         return;
     }
 
@@ -327,9 +360,31 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     const bool early = wave < NCOMP / 2;
 
     // Row-major walk of a granule: the three column-group fragments of one input row are read once and meet every weight fragment that
-    // row pairs with (both layers, one ky each) before the next row is touched -- 12 + 6 x 4 registers of operands live at a time.
+    // row pairs with (both layers, one ky each) before the next row is touched.
+    // Round 3: a STATIC software pipeline.  Round 2's loop read each pair of weight fragments right in front of the six MFMAs that use
+    // them (the compiler sinks LDS reads towards their use to save registers), so every six MFMAs met a full LDS latency: the stamps
+    // show 108 MFMAs of a SIMD's two waves taking 2.2-2.4 k cycles (20-22 per MFMA, the pipe does 16).  Now the walk is a fixed list
+    // of stages -- one weight fragment x three column groups each -- and the fragment of stage k + WDEPTH is requested before the
+    // MFMAs of stage k; a sched_barrier after every stage keeps the compiler from undoing the distance.  The next row's pixel
+    // fragments are requested at the first stage of the current row, as before.
+    constexpr int WDEPTH = 3, NWREG = WDEPTH + 1;
     // one (chunk, kx) granule on an external chunk staged at `sb`: staged row j holds stream row 8s-2+j; layer 0 (row 8s+w) reads
-    // j = w+1+ky, layer 1 (row 8s+w-1) reads j = w+ky
+    // j = w+1+ky, layer 1 (row 8s+w-1) reads j = w+ky.  Stage order: row d = 0..3: [layer 0, ky = d-1 (d >= 1)] [layer 1, ky = d (d <= 2)]
+    struct ExtStage { int d, layer, n, frag, first; };
+    auto ext_stage = [](int k) constexpr -> ExtStage {
+        int i = 0;
+        for (int d = 0; d < 4; ++d) {
+            bool first = true;
+            if (d >= 1)
+                for (int n = 0; n < NB0; ++n, ++i, first = false)
+                    if (i == k) return ExtStage{d, 0, n, (d - 1) * NB0 + n, first};
+            if (d <= 2)
+                for (int n = 0; n < NB1; ++n, ++i, first = false)
+                    if (i == k) return ExtStage{d, 1, n, 3 * NB0 + d * NB1 + n, first};
+        }
+        return ExtStage{-1, 0, 0, 0, 0};
+    };
+    constexpr int NEXTST = 3 * (NB0 + NB1);
     auto ext_granule = [&](auto KXc, const char* sb, const char* ws) {
         constexpr int KX = decltype(KXc)::value;
         const char* rb = sb + wave * ROWB;
@@ -341,33 +396,25 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 if ((KX == 0 && cg == 0 && edge_l) || (KX == 2 && cg == 2 && edge_r)) x[cg] = bf16x8{};
             }
         };
-        bf16x8 xc[3], xn[3];
-        load_row(0, xc);
+        auto ldw = [&](int frag) { return *reinterpret_cast<const bf16x8*>(ws + frag * 1024 + lane * 16); };
+        bf16x8 xr[2][3], wq[NWREG];
+        load_row(0, xr[0]);
+        static_for<WDEPTH>([&](auto K) { wq[decltype(K)::value] = ldw(ext_stage(decltype(K)::value).frag); });
+        static_for<NEXTST>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            constexpr ExtStage st = ext_stage(k);
+            if constexpr (st.first && st.d < 3) load_row(st.d + 1, xr[(st.d + 1) & 1]);       // next row's fragments fly under this row's MFMAs
+            if constexpr (k + WDEPTH < NEXTST) wq[(k + WDEPTH) % NWREG] = ldw(ext_stage(k + WDEPTH).frag);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            if (d < 3) load_row(d + 1, xn);                  // next row's fragments fly under this row's MFMAs
-            if (d >= 1) {
-#pragma unroll
-                for (int n = 0; n < NB0; ++n) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + ((d - 1) * NB0 + n) * 1024 + lane * 16);
-#pragma unroll
-                    for (int cg = 0; cg < 3; ++cg) a0[n][cg] = mma16(wf, xc[cg], a0[n][cg]);
-                }
+            for (int cg = 0; cg < 3; ++cg) {
+                if constexpr (st.layer == 0) a0[st.n][cg] = mma16(wq[k % NWREG], xr[st.d & 1][cg], a0[st.n][cg]);
+                else a1[st.n][cg] = mma16(wq[k % NWREG], xr[st.d & 1][cg], a1[st.n][cg]);
             }
-            if (d <= 2) {
-#pragma unroll
-                for (int n = 0; n < NB1; ++n) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + (3 * NB0 + d * NB1 + n) * 1024 + lane * 16);
-#pragma unroll
-                    for (int cg = 0; cg < 3; ++cg) a1[n][cg] = mma16(wf, xc[cg], a1[n][cg]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);               // keep the scheduler from hoisting the whole granule's operand reads (168-register budget)
-#pragma unroll
-            for (int cg = 0; cg < 3; ++cg) xc[cg] = xn[cg];
-        }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
     // one kx granule of layer 1 on layer 0's output: ring rows r1-1, r1, r1+1 with r1 = 8s+w-1
+    constexpr int NRINGST = 3 * NB1;
     auto ring_granule = [&](auto KXc, int s, const char* ws) {
         constexpr int KX = decltype(KXc)::value;
         auto load_row = [&](int ky, bf16x8 (&x)[3]) {
@@ -379,21 +426,19 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 if ((KX == 0 && cg == 0 && edge_l) || (KX == 2 && cg == 2 && edge_r)) x[cg] = bf16x8{};
             }
         };
-        bf16x8 xc[3], xn[3];
-        load_row(0, xc);
+        auto ldw = [&](int frag) { return *reinterpret_cast<const bf16x8*>(ws + frag * 1024 + lane * 16); };
+        bf16x8 xr[2][3], wq[NWREG];
+        load_row(0, xr[0]);
+        static_for<WDEPTH>([&](auto K) { wq[decltype(K)::value] = ldw(decltype(K)::value); });
+        static_for<NRINGST>([&](auto K) {
+            constexpr int k = decltype(K)::value;            // stage k: ky = k / NB1, cout block n = k % NB1, fragment k
+            constexpr int ky = k / NB1, n = k % NB1;
+            if constexpr (n == 0 && ky < 2) load_row(ky + 1, xr[(ky + 1) & 1]);
+            if constexpr (k + WDEPTH < NRINGST) wq[(k + WDEPTH) % NWREG] = ldw(k + WDEPTH);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            if (ky < 2) load_row(ky + 1, xn);
-#pragma unroll
-            for (int n = 0; n < NB1; ++n) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + (ky * NB1 + n) * 1024 + lane * 16);
-#pragma unroll
-                for (int cg = 0; cg < 3; ++cg) a1[n][cg] = mma16(wf, xc[cg], a1[n][cg]);
-            }
+            for (int cg = 0; cg < 3; ++cg) a1[n][cg] = mma16(wq[k % NWREG], xr[ky & 1][cg], a1[n][cg]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cg = 0; cg < 3; ++cg) xc[cg] = xn[cg];
-        }
+        });
     };
     // Granule boundary of a compute wave: its LDS reads / writes of the finished granule are done, then the barrier that publishes the
     // loaders' pieces.  No vmcnt here: a compute wave issues no DMA, and its epilogue stores drain on their own.
@@ -650,9 +695,11 @@ int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H
     if (tail && (!out.p || !out.blk || out.coff != 0 || out.cs % 32 != 0 || alpha == 0.f)) return ctx->fail(SR_ERR_INVALID, "fused dense-block tail: bad destination view");
     if (skip_o.p && (!skip_o.blk || skip_o.coff != 0 || skip_o.cs % 32 != 0)) return ctx->fail(SR_ERR_INVALID, "fused dense-block tail: bad skip view");
     if (!ctx->zero_page) {
-        ctx->zero_page = ctx->dalloc(4096);
+        // separator / out-of-stream rows are staged from here with the same chunk offset as real rows: (EXT - 1) * 3 KiB + one 3 KiB row
+        static_assert(ZERO_PAGE_BYTES >= 6 * ROWB, "zero page covers every chunk offset");
+        ctx->zero_page = ctx->dalloc(ZERO_PAGE_BYTES);
         if (!ctx->zero_page) return SR_ERR_OOM;
-        SR_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, 4096, st));
+        SR_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, ZERO_PAGE_BYTES, st));
     }
     int ncu = ctx->num_cus;
     if (ncu <= 0) {

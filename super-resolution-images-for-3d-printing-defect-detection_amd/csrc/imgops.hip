@@ -935,7 +935,10 @@ __global__ void __launch_bounds__(256) spectral_wc_partial_kernel(const float* a
 
 int spectral_l1_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float* out, hipStream_t st) {
     if (C != 3) return ctx->fail(SR_ERR_INVALID, "spectral loss: built for 3 channels (the FFT runs over the (W, C) axes)");
-    if (B <= 0 || H <= 0 || W <= 0 || W > 4096) return ctx->fail(SR_ERR_INVALID, "spectral loss: bad shape");
+    // the kernel keeps one image row and its twiddles in LDS: 56 bytes per pixel of width, 160 KiB per CU
+    constexpr int SPECTRAL_MAX_W = 160 * 1024 / 56;
+    if (B <= 0 || H <= 0 || W <= 0) return ctx->fail(SR_ERR_INVALID, "spectral loss: bad shape");
+    if (W > SPECTRAL_MAX_W) return ctx->fail(SR_ERR_INVALID, "spectral loss: image width " + std::to_string(W) + " exceeds " + std::to_string(SPECTRAL_MAX_W) + " (one row + twiddles must fit a CU's 160 KiB of LDS)");
     const int64_t rows = (int64_t)B * H;
     float* partial;
     int rc = reduce_scratch(ctx, (size_t)rows, &partial);

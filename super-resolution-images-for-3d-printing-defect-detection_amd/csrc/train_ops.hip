@@ -372,7 +372,9 @@ int zero_insert2_launch(sr_ctx* ctx, const float* dy, int B, int H, int W, int C
 
 int spectral_l1_bwd_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float scale, float* da, hipStream_t st) {
     if (C != 3) return ctx->fail(SR_ERR_INVALID, "spectral loss: built for 3 channels");
-    if (B <= 0 || H <= 0 || W <= 0 || W > 2048) return ctx->fail(SR_ERR_INVALID, "spectral loss backward: bad shape");
+    constexpr int SPECTRAL_BWD_MAX_W = 160 * 1024 / 80;       // 80 bytes of LDS per pixel of width
+    if (B <= 0 || H <= 0 || W <= 0) return ctx->fail(SR_ERR_INVALID, "spectral loss backward: bad shape");
+    if (W > SPECTRAL_BWD_MAX_W) return ctx->fail(SR_ERR_INVALID, "spectral loss backward: image width " + std::to_string(W) + " exceeds " + std::to_string(SPECTRAL_BWD_MAX_W) + " (80 B of LDS per pixel of width)");
     const int64_t rows = (int64_t)B * H;
     const size_t lds = sizeof(float) * (size_t)(2 * W + 18 * W);
     auto kern = spectral_wc_bwd_kernel;

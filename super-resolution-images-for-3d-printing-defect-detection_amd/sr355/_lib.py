@@ -36,9 +36,10 @@ SIGNATURES = {
     "sr_last_error": (C.c_char_p, [_vp]),
     "sr_mem_info": (_i, [_vp, _i64p, _i64p]),
     "sr_last_forward_ms": (_i, [_vp, _fp]),
-    "sr_debug_set_stamp_buffer": (_i, [_vp, _vp]),
+    "sr_debug_set_stamp_buffer": (_i, [_vp, _vp, _i64]),
+    "sr_debug_stamp_bytes_needed": (_i64, [_i, _i64]),
     "sr_measure_clock": (_i, [_vp, _fp, _vp]),
-    "sr_debug_set_chain_stamp_buffer": (_i, [_vp, _vp]),
+    "sr_debug_set_chain_stamp_buffer": (_i, [_vp, _vp, _i64]),
     "sr_debug_set_fused": (_i, [_vp, _i, _i]),
     "sr_debug_set_alloc_cap": (_i, [_vp, _i64]),
     "sr_profile_begin": (_i, [_vp]),

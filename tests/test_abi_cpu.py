@@ -49,3 +49,17 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libsr355.so"))
     with pytest.raises(ImportError):
         _lib.load()
+
+
+def test_stamp_buffer_sizes_are_exported_and_the_setters_take_a_capacity():
+    """the diagnostic stamp setters carry the buffer's capacity; a launch / a buffer that would not fit is refused
+    (tests/test_runtime_gpu.py runs the refusal on a context).  The pure size function answers without a GPU."""
+    from sr355 import _lib
+    lib = _lib.load()
+    assert lib.sr_debug_stamp_bytes_needed(0, 63504) == 63504 * 16 * 8          # round 2's fault: 63 504 workgroups x 16 stamps
+    assert lib.sr_debug_stamp_bytes_needed(1, 0) == 64 * 4 * 64 * 4 * 8 == 524288
+    assert lib.sr_debug_stamp_bytes_needed(0, -1) == -1 and lib.sr_debug_stamp_bytes_needed(7, 1) == -1
+    assert len(_lib.SIGNATURES["sr_debug_set_stamp_buffer"][1]) == 3 and len(_lib.SIGNATURES["sr_debug_set_chain_stamp_buffer"][1]) == 3
+    # no context: invalid, and nothing is dereferenced
+    assert lib.sr_debug_set_stamp_buffer(None, None, 0) == _lib.SR_ERR_INVALID
+    assert lib.sr_debug_set_chain_stamp_buffer(None, None, 0) == _lib.SR_ERR_INVALID

@@ -382,7 +382,13 @@ def test_vgg16_fit_frozen_base(ctx, tmp_path):
     assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.isfinite(runs[0][0]).all()
     aug = FineTunedVGG16._augment(X[:4], np.random.default_rng(1))
     assert aug.shape == X[:4].shape and aug.min() >= 0 and aug.max() <= 1 and not np.array_equal(aug, X[:4])
+    # the notebook's call (VGG16.ipynb:L161-165): setup_model(train_last_n_layers=6, base_trainable=True).  In the reference the base
+    # stays frozen all the same (VGG16_model.py:76-82; 131 842 trainable parameters, VGG16.ipynb:L152): same head-only training,
+    # bit for bit the run without the flag
     b = FineTunedVGG16()
-    b.setup_model(input_shape=(32, 32, 3), base_trainable=True)
-    with pytest.raises(NotImplementedError):
-        b.fit(X, y, Xv, yv)
+    b.setup_model(input_shape=(32, 32, 3), num_classes=2, train_last_n_layers=6, base_trainable=True, dropout_rate=0.0, learning_rate=1e-3)
+    assert b.count_params() == 14846530 and b.count_params(trainable_only=True) == 131842 and b.trainable_layers() == ["dense", "predictions"]
+    hb = b.fit(X, y, Xv, yv, batch_size=8, epochs=3, use_augmentation=False, seed=5)
+    assert hb.history["loss"] == hist.history["loss"] and hb.history["val_accuracy"] == hist.history["val_accuracy"]
+    assert all(np.array_equal(b.weights[n][0], w0[n][0]) for n in w0 if n.startswith("block"))
+    assert all(np.array_equal(b.weights[n][0], m.weights[n][0]) for n in ("dense", "predictions"))

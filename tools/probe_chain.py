@@ -26,10 +26,10 @@ for _ in range(2):
     m.forward(x)
 torch.cuda.synchronize()
 buf = torch.zeros(64 * 4 * 64 * 4, dtype=torch.int64, device="cuda")
-ctx.check(ctx.lib.sr_debug_set_chain_stamp_buffer(ctx.h, buf.data_ptr()))
+ctx.check(ctx.lib.sr_debug_set_chain_stamp_buffer(ctx.h, buf.data_ptr(), buf.numel() * 8))
 m.forward(x)
 torch.cuda.synchronize()
-ctx.check(ctx.lib.sr_debug_set_chain_stamp_buffer(ctx.h, None))
+ctx.check(ctx.lib.sr_debug_set_chain_stamp_buffer(ctx.h, None, 0))
 t = buf.cpu().numpy().reshape(64, 4, 64, 4).astype(np.int64)
 ngr = 18 if mask == 1 else 12                    # granules per step of the LAST launch that wrote the buffer (dense3's pair)
 valid = t[:, :, :, 0] > 0

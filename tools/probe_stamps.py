@@ -19,9 +19,9 @@ x = ctx.to_device(np.random.default_rng(0).uniform(-1, 1, (B, 48, 48, 3)).astype
 m.forward(x); torch.cuda.synchronize()
 nwg_max = B * 9 * 16 * 4 * 4
 buf = torch.zeros(nwg_max * 16, dtype=torch.int64, device="cuda")
-ctx.lib.sr_debug_set_stamp_buffer(ctx.h, buf.data_ptr())
+ctx.lib.sr_debug_set_stamp_buffer(ctx.h, buf.data_ptr(), buf.numel() * 8)
 m.forward(x); torch.cuda.synchronize()
-ctx.lib.sr_debug_set_stamp_buffer(ctx.h, None)
+ctx.lib.sr_debug_set_stamp_buffer(ctx.h, None, 0)
 # the buffer holds the LAST launch that wrote each workgroup slot; the trunk convs (2646 / 3969 WGs) were overwritten by later, bigger
 # launches -- so instead stamp individual layers by running a model whose last 3x3 conv is the one of interest
 print("stamps of the last conv launches (final_conv1: 64->64 at 192x192 ...) not separated; see per-layer probes below")
@@ -32,9 +32,9 @@ def probe(cin, cout, label):
     w = (np.random.default_rng(1).standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
     ctx.conv2d(xx, w, None, act="relu"); torch.cuda.synchronize()
     buf.zero_()
-    ctx.lib.sr_debug_set_stamp_buffer(ctx.h, buf.data_ptr())
+    ctx.lib.sr_debug_set_stamp_buffer(ctx.h, buf.data_ptr(), buf.numel() * 8)
     ctx.conv2d(xx, w, None, act="relu"); torch.cuda.synchronize()
-    ctx.lib.sr_debug_set_stamp_buffer(ctx.h, None)
+    ctx.lib.sr_debug_set_stamp_buffer(ctx.h, None, 0)
     s = buf.cpu().numpy().reshape(-1, 16)
     s = s[s[:, 0] != 0]
     d = s - s[:, :1]
