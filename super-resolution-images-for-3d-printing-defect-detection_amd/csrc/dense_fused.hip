@@ -47,7 +47,7 @@ struct ChainParams {
     const char* zero;                  // ZERO_PAGE_BYTES of zeros: DMA source of separator / out-of-stream rows (same chunk offsets as real rows)
     int B, H;
     int imgs_per_wg; unsigned magic;   // g / (H+1) == umulhi(g, magic) for every stream row index that occurs
-    float alpha, xscale, beta_o;       // MODE 1: out = alpha * (acc + bias + xscale * x) + beta_o * so
+    float alpha, xscale, oscale;       // MODE 1: out = alpha * (acc + bias + xscale * x + oscale * so); xscale = beta_x / alpha, oscale = beta_o / alpha, both exact in bf16
     int dbg_flags;                     // diagnostic builds only (env SR355_CHAIN_DBG_FLAGS): 1 = drop the tail's output stores, 2 = skip the external granules' MFMA bodies (timing experiments; results are wrong)
     unsigned long long* dbg;           // diagnostic builds only (sr_debug_set_chain_stamp_buffer): s_memtime stamps, [wg < 64][wave 0 / 5 / 8 / 11][granule < 64][4]
 };
@@ -159,6 +159,9 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     // ---- one-time LDS state: the ring starts as zeros (rows above the first image), biases parked for the epilogues
     for (int u = tid; u < WINR * ROWB / 16; u += NTHR) *reinterpret_cast<f32x4*>(win + u * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < NBT * 16) lbias[tid] = p.bias[tid];
+    // the compute waves read the biases (accumulator start values) before the first granule barrier: publish them now
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     auto row_of = [&](int g, int& img, int& y) -> bool {          // stream row -> (image, row); false: separator / outside the stream
         if (g < 0 || g >= N) return false;
@@ -346,7 +349,6 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     const int off_r = edge_r ? offk[1] : offk[2];
 
     f32x4 a0[NB0][3], a1[NB1][3];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // Output rows leave through LDS.  In the MFMA result layout lane (px, q) holds 8 channels of pixel px, so neighbouring lanes are 64 B
     // apart and a 16-byte global store per lane reaches memory as 64 separate 16-byte writes: ~600 cycles per store instruction and wave
@@ -355,10 +357,30 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     // back 16 B per lane in lane order, which stores -- and, for the RRDB skip, loads -- whole cache lines.  The slots live in the staging
     // buffer of the external chunk just finished, which nobody touches between the barrier after the last external granule and the one
     // that opens the next step (4 KiB per wave).
-    const int t_a = px * 64 + 16 * ((q >> 1) ^ ((px >> 1) & 3)) + (q & 1) * 8;     // slot offset of channels [4q, 4q+4) of pixel px; channels [16+4q, ..) are at t_a ^ 32
-    const int t_line = (lane >> 2) * 64 + 16 * ((lane & 3) ^ ((lane >> 3) & 3));   // slot offset of the piece's bytes [16 l, 16 l + 16) for lane l
-    const bool early = wave < NCOMP / 2;
+    // t_a: slot offset of channels [4q, 4q+4) of pixel px (channels [16+4q, ..) are at t_a ^ 32); t_line: slot offset of the piece's bytes
+    // [16 l, 16 l + 16) for lane l.  Recomputed where they are used (once per step): kept live across the MFMA loops they were the values
+    // hipcc spilled to scratch at the 168-register budget.
+    auto transpose_offsets = [&](int& t_a, int& t_line) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int px_ = l & 15, q_ = l >> 4;
+        t_a = px_ * 64 + 16 * ((q_ >> 1) ^ ((px_ >> 1) & 3)) + (q_ & 1) * 8;
+        t_line = (l >> 2) * 64 + 16 * ((l & 3) ^ ((l >> 3) & 3));
+    };
 
+    // xscale * identity as MFMA A fragments: lane (cout i = lane & 15, k-quarter = lane >> 4) holds channels 8 (lane >> 4) + j; fragment h maps
+    // channel 16 h + i of a 32-channel chunk onto cout i of a 16-cout block: its only non-zero element in this lane is j = 16 h + i - 8 q, if
+    // that is in [0, 8).  Built where it is used (a few selects) rather than held in eight registers.  xscale (5 or 25 in this graph) is
+    // exact in bf16: the host refuses anything that is not.
+    auto xfold = [&](int h, float scale) {
+        const bf16_t xs_b = (bf16_t)scale;
+        int j0 = 16 * h + px - 8 * q;
+        asm volatile("" : "+v"(j0));          // not loop invariant as far as hipcc can tell: hoisted, the fragments were spilled to scratch
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = j == j0 ? xs_b : (bf16_t)0.f;
+        return f;
+    };
     // Row-major walk of a granule: the three column-group fragments of one input row are read once and meet every weight fragment that
     // row pairs with (both layers, one ky each) before the next row is touched.
     // Round 3: a STATIC software pipeline.  Round 2's loop read each pair of weight fragments right in front of the six MFMAs that use
@@ -385,8 +407,9 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
         return ExtStage{-1, 0, 0, 0, 0};
     };
     constexpr int NEXTST = 3 * (NB0 + NB1);
-    auto ext_granule = [&](auto KXc, const char* sb, const char* ws) {
+    auto ext_granule = [&](auto KXc, auto FOLDc, const char* sb, const char* ws) {
         constexpr int KX = decltype(KXc)::value;
+        constexpr int FOLD = KX == 1 ? decltype(FOLDc)::value : -1;      // the centre tap carries the skip
         const char* rb = sb + wave * ROWB;
         auto load_row = [&](int d, bf16x8 (&x)[3]) {
 #pragma unroll
@@ -409,6 +432,18 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             for (int cg = 0; cg < 3; ++cg) {
                 if constexpr (st.layer == 0) a0[st.n][cg] = mma16(wq[k % NWREG], xr[st.d & 1][cg], a0[st.n][cg]);
                 else a1[st.n][cg] = mma16(wq[k % NWREG], xr[st.d & 1][cg], a1[st.n][cg]);
+            }
+            // The block's own input x (channels [0, 64) = chunks 0, 1) is layer 1's skip: xscale * x(centre pixel) joins the accumulators of
+            // cout blocks 2 FOLD, 2 FOLD + 1 as one more "tap" whose weight fragments are xscale times the identity (xfold[], built in
+            // registers) against the centre row's fragments (staged row w + 1 = d 1, kx 1) -- six MFMAs where round 2 spent ~100 vector
+            // instructions per wave and chunk (stamps: +1.0 k cycles on the two granules that carried it).
+            if constexpr (FOLD >= 0 && st.d == 1 && st.layer == 1 && st.n == NB1 - 1) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bf16x8 f = xfold(h, p.xscale);
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) a1[2 * FOLD + h][cg] = mma16(f, xr[1][cg], a1[2 * FOLD + h][cg]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -448,52 +483,48 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     };
 
     int nch = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    auto chunk = [&](auto FOLDc, int& Gr) {
+        const char* sb = stg + (nch % NSB) * STGB;
 #pragma unroll
-        for (int n = 0; n < NB0; ++n)
-#pragma unroll
-            for (int cg = 0; cg < 3; ++cg) a0[n][cg] = zero4;
-#pragma unroll
-        for (int n = 0; n < NB1; ++n)
-#pragma unroll
-            for (int cg = 0; cg < 3; ++cg) a1[n][cg] = zero4;
-
-#pragma nounroll
-        for (int c = 0; c < EXT; ++c, ++nch) {
-            const char* sb = stg + (nch % NSB) * STGB;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx, ++G) {
-                CHAIN_STAMP(0);
-                sync();
-                CHAIN_STAMP(1);
-                CHAIN_STAMP(2);
-                const char* ws = wr + (G % NWS) * WSLOT;
-                if (STAMP && (p.dbg_flags & 2)) { /* timing experiment: loaders alone */ }
-                else if (kx == 0) ext_granule(std::integral_constant<int, 0>{}, sb, ws);
-                else if (kx == 1) ext_granule(std::integral_constant<int, 1>{}, sb, ws);
-                else ext_granule(std::integral_constant<int, 2>{}, sb, ws);
-                CHAIN_STAMP(3);
-            }
-            if (MODE == 1 && c < 2) {
-                // the block's own input x (channels [0,64) = chunks 0,1) is layer 1's skip: fold xscale * x(centre pixel) into the accumulators
-                // of cout blocks 2c, 2c+1 from the staged image (row j = w+1)
-                // (branch-free in c: a run-time choice of the accumulator block made hipcc merge the accumulators through phis and copy them)
-                const float sc0 = c == 0 ? p.xscale : 0.f, sc1 = c == 0 ? 0.f : p.xscale;
-#pragma unroll
-                for (int cg = 0; cg < 3; ++cg)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int slice = h * 2 + (q >> 1);
-                        const bf16x4 xk = *reinterpret_cast<const bf16x4*>(sb + (wave + 1) * ROWB + cg * 1024 + 64 * px + 16 * (slice ^ (2 * ((px >> 2) & 1))) + (q & 1) * 8);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a1[h][cg][e] += sc0 * (float)xk[e];
-                            a1[2 + h][cg][e] += sc1 * (float)xk[e];
-                        }
-                    }
-            }
+        for (int kx = 0; kx < 3; ++kx, ++Gr) {
+            CHAIN_STAMP(0);
+            sync();
+            CHAIN_STAMP(1);
+            CHAIN_STAMP(2);
+            const char* ws = wr + (Gr % NWS) * WSLOT;
+            if (STAMP && (p.dbg_flags & 2)) { /* timing experiment: loaders alone */ }
+            else if (kx == 0) ext_granule(std::integral_constant<int, 0>{}, FOLDc, sb, ws);
+            else if (kx == 1) ext_granule(std::integral_constant<int, 1>{}, FOLDc, sb, ws);
+            else ext_granule(std::integral_constant<int, 2>{}, FOLDc, sb, ws);
+            CHAIN_STAMP(3);
         }
-        // ---- layer 0 epilogue: bias + ReLU -> bf16 -> ring row (8s+w) mod 10 (zeros on separator / out-of-stream rows)
+        ++nch;
+    };
+    for (int s = 0; s < nsteps; ++s) {
+        // accumulators start at the bias (the epilogues then have no bias add)
+#pragma unroll
+        for (int n = 0; n < NB0; ++n) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) a0[n][cg] = b;
+        }
+#pragma unroll
+        for (int n = 0; n < NB1; ++n) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + (NB0 + n) * 16 + 4 * q);
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) a1[n][cg] = b;
+        }
+        if constexpr (MODE == 1) {
+            static_assert(MODE == 0 || EXT >= 2, "the tail's skip spans chunks 0 and 1");
+            chunk(std::integral_constant<int, 0>{}, G);
+            chunk(std::integral_constant<int, 1>{}, G);
+#pragma nounroll
+            for (int c = 2; c < EXT; ++c) chunk(std::integral_constant<int, -1>{}, G);
+        } else {
+#pragma nounroll
+            for (int c = 0; c < EXT; ++c) chunk(std::integral_constant<int, -1>{}, G);
+        }
+        // ---- layer 0 epilogue: ReLU -> bf16 -> ring row (8s+w) mod 10 (zeros on separator / out-of-stream rows)
         {
             const int g0 = 8 * s + wave;
             int img, y;
@@ -505,9 +536,8 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 f32x4 v[NB0];
 #pragma unroll
                 for (int n = 0; n < NB0; ++n) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[n][e] = real ? fmaxf(a0[n][cg][e] + b[e], 0.f) : 0.f;
+                    for (int e = 0; e < 4; ++e) v[n][e] = real ? fmaxf(a0[n][cg][e], 0.f) : 0.f;
                     const bf16x4 o = {(bf16_t)v[n][0], (bf16_t)v[n][1], (bf16_t)v[n][2], (bf16_t)v[n][3]};
                     const int slice = n * 2 + (q >> 1);
                     *reinterpret_cast<bf16x4*>(wrow + cg * 1024 + 64 * px + 16 * (slice ^ (2 * ((px >> 2) & 1))) + (q & 1) * 8) = o;
@@ -526,10 +556,11 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             }
         }
         char* const tb = stg + ((nch + NSB - 1) % NSB) * STGB + wave * 4096;       // transposition slots (free staging buffer, see above)
-        // the other skip tensor of an RRDB's last block (beta_o * so) is folded into layer 1's accumulators as (beta_o / alpha) * so while
-        // layer 1 runs on the ring: column group kx's two 16-byte loads are issued around the barrier of ring granule kx (early waves
-        // behind it, late waves in front of it) and consumed after that granule's MFMAs -- eight registers for one granule
-        u32x4 sl[2];
+        // The other skip tensor of an RRDB's last block (beta_o * so) joins layer 1's accumulators as (beta_o / alpha) * so while layer 1 runs
+        // on the ring, the same way x does: column group kx's two 1 KiB pieces (chunks 0 and 1 of the wave's row) come by LDS-DMA in the
+        // staged pixel layout into the wave's transposition slots 0 / 1 -- requested right behind the barrier of ring granule kx -- and meet
+        // oscale * identity fragments in four MFMAs after that granule's own.  (Round 2 held the
+        // two pieces in eight registers through the granule, transposed them through LDS and spent ~50 vector instructions per granule.)
         const char* sob = nullptr;
         if (MODE == 1 && HAS_O) {
             int img, y;
@@ -537,41 +568,43 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
         }
         auto so_fetch = [&](int cg) {
             if (MODE == 1 && HAS_O && sob) {
-                sl[0] = *reinterpret_cast<const u32x4*>(sob + cg * 1024 + lane * 16);
-                sl[1] = *reinterpret_cast<const u32x4*>(sob + ROWB + cg * 1024 + lane * 16);
+                int l = lane;
+                asm volatile("" : "+v"(l));
+                const int ls = 64 * (l >> 2) + 16 * ((l & 3) ^ (2 * ((l >> 4) & 1)));      // the loaders' source swizzle
+                dma(sob + cg * 1024 + ls, tb);
+                dma(sob + ROWB + cg * 1024 + ls, tb + 1024);
             }
         };
         // ---- layer 1 on layer 0's output
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx, ++G) {
             CHAIN_STAMP(0);
-            if (!early) so_fetch(kx);
             sync();
             CHAIN_STAMP(1);
-            if (early) so_fetch(kx);
+            // behind the barrier, every wave: the slots sit in the staging buffer of the last external chunk, which other waves read until
+            // they have passed the barrier of the first ring granule
+            so_fetch(kx);
             CHAIN_STAMP(2);
             const char* ws = wr + (G % NWS) * WSLOT;
             if (kx == 0) ring_granule(std::integral_constant<int, 0>{}, s, ws);
             else if (kx == 1) ring_granule(std::integral_constant<int, 1>{}, s, ws);
             else ring_granule(std::integral_constant<int, 2>{}, s, ws);
             if (MODE == 1 && HAS_O && sob) {
-                const float sc2 = p.beta_o / p.alpha;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's own two pieces (and its long-finished output stores)
+                int l = lane;
+                asm volatile("" : "+v"(l));
+                const int pxl = l & 15, ql = l >> 4;
+                const int offc = 64 * pxl + 16 * (ql ^ (2 * ((pxl >> 2) & 1)));          // centre-tap pixel fragment inside a 1 KiB piece
 #pragma unroll
-                for (int h = 0; h < NB1 / 2; ++h) {
-                    *reinterpret_cast<u32x4*>(tb + h * 1024 + t_line) = sl[h];
-                    asm volatile("" ::: "memory");
-                    const bf16x4 ka = *reinterpret_cast<const bf16x4*>(tb + h * 1024 + t_a);
-                    const bf16x4 kc = *reinterpret_cast<const bf16x4*>(tb + h * 1024 + (t_a ^ 32));
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const bf16x8 xo = *reinterpret_cast<const bf16x8*>(tb + c2 * 1024 + offc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a1[2 * h][kx][e] += sc2 * (float)ka[e];
-                        a1[2 * h + 1][kx][e] += sc2 * (float)kc[e];
-                    }
+                    for (int h = 0; h < 2; ++h) a1[2 * c2 + h][kx] = mma16(xfold(h, p.oscale), xo, a1[2 * c2 + h][kx]);
                 }
             }
             CHAIN_STAMP(3);
         }
-        // ---- layer 1 epilogue (row 8s+w-1): bias (+ ReLU | * alpha) -> bf16 -> transposition slot -> whole-line stores
+        // ---- layer 1 epilogue (row 8s+w-1): ReLU | * alpha -> bf16 -> transposition slot -> whole-line stores
         {
             int img, y;
             const bool real = row_of(8 * s + wave - 1, img, y);
@@ -579,6 +612,8 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 const int64_t rowi = (int64_t)(img0 + img) * H + y;
                 char* const grow = MODE == 0 ? const_cast<char*>(p.in) + (rowi * p.in_nch + EXT + 1) * ROWB : p.out + rowi * p.out_nch * ROWB;
                 const float alpha = p.alpha;
+                int t_a, t_line;
+                transpose_offsets(t_a, t_line);
 #pragma unroll
                 for (int cg = 0; cg < 3; ++cg)
 #pragma unroll
@@ -587,10 +622,9 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int n = 2 * h + u;
-                            const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + (NB0 + n) * 16 + 4 * q);
                             f32x4 v;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = MODE == 0 ? fmaxf(a1[n][cg][e] + b[e], 0.f) : alpha * (a1[n][cg][e] + b[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = MODE == 0 ? fmaxf(a1[n][cg][e], 0.f) : alpha * a1[n][cg][e];
                             *reinterpret_cast<bf16x4*>(slot + (t_a ^ (32 * u))) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         }
                         asm volatile("" ::: "memory");                 // the read-back below is of other lanes' writes: keep the order
@@ -618,7 +652,7 @@ int launch_chain(sr_ctx* ctx, const ChainParams& p, bool has_o, int nwg, hipStre
         auto k = chain2_kernel<EXT, NB0, NB1, MODE, MODE == 1, true>;
         if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), lds)) return rc;
         ChainParams q = p;
-        if (MODE == 1 && !has_o) { q.so = p.in; q.so_nch = p.in_nch; q.beta_o = 0.f; }   // the stamped build always carries the skip loads
+        if (MODE == 1 && !has_o) { q.so = p.in; q.so_nch = p.in_nch; q.oscale = 0.f; }   // the stamped build always carries the skip loads
         hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), lds, st, q);
     } else if (has_o) {
         auto k = chain2_kernel<EXT, NB0, NB1, MODE, true, false>;
@@ -718,7 +752,13 @@ int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H
     const int nwg = (B + p.imgs_per_wg - 1) / p.imgs_per_wg;
     p.magic = (unsigned)(((1ull << 32) + (unsigned)H) / (unsigned)(H + 1));                 // ceil(2^32 / (H+1)): exact quotient for g < 2^32 / (H+1)
     if ((int64_t)p.imgs_per_wg * (H + 1) + 16 >= (1ll << 20)) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: stream too long");
-    p.alpha = alpha; p.xscale = tail ? beta_x / alpha : 0.f; p.beta_o = beta_o;
+    p.alpha = alpha; p.xscale = tail ? beta_x / alpha : 0.f; p.oscale = tail && skip_o.p ? beta_o / alpha : 0.f;
+    for (float sc : {p.xscale, p.oscale}) {   // the skips join the accumulators as scale * identity MFMA fragments in bf16: only exactly representable ratios (5 and 25 here)
+        uint32_t u = (uint32_t)bf16_host(sc) << 16;
+        float back;
+        memcpy(&back, &u, 4);
+        if (back != sc) return ctx->fail(SR_ERR_INVALID, "fused dense-block tail: beta / alpha is not exactly representable in bf16");
+    }
     p.dbg = ctx->chain_stamp_buf;
     { const char* f = getenv("SR355_CHAIN_DBG_FLAGS"); p.dbg_flags = f ? atoi(f) : 0; }
     if (p.dbg && ctx->chain_stamp_skip >= 0 && ctx->chain_stamp_skip-- != 0) p.dbg = nullptr;   // stamp one chosen launch only

@@ -252,6 +252,53 @@ def test_esrgan_train_step(ctx, cfg):
     assert tr.step == 1 and GT.staircase_lr(1e-4, 9999) == 1e-4 and GT.staircase_lr(1e-4, 10000) == 5e-5
 
 
+def test_esrgan_train_step_at_the_baseline_configuration(ctx):
+    """BASELINE configs[3] at its stated size: x4, NB = 23, G = 32, both SelfAttention layers, 16 LR patches
+    24x24 -> 96x96 per GPU, fp32 (ESRGAN_model.py:475-533 with the defaults of :108-112).  Shapes and the parameter bucket
+    (16 930 019 generator + 658 305 discriminator parameters, ESRGAN.ipynb:L636/L693), finite losses, two runs from the same state
+    give the same numbers bit for bit; then, on 2 of the 16 patches (what the fp64 CPU oracle finishes in seconds at this depth), the
+    six loss terms and sampled generator / discriminator gradients against oracle/train.py."""
+    from sr355 import gan_train as GT
+    scale, nb, G = 4, 23, 32
+    gw, dw, vw = _gan_setup(scale, nb, G)
+    # glorot-initialised RRDBs have gain ~1.2 per block: 23 of them would make the losses astronomically large; damp the residual branches
+    gw = {n: ((k * 0.1, b * 0.1) if n.endswith("_conv5") else (k, b)) for n, (k, b) in gw.items()}
+    count = lambda w: sum(int(np.prod(k.shape)) + int(np.prod(b.shape)) for k, b in w.values())
+    assert count(gw) == 16930019 and count(dw) == 658305
+    rng = np.random.default_rng(42 + 3)
+    lr = rng.uniform(-1, 1, (16, 24, 24, 3)).astype(np.float32)
+    hr = rng.uniform(-1, 1, (16, 96, 96, 3)).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        tr = GT.ESRGANTrainer(ctx, gw, dw, vw, scale, nb, attention=True, g_lr=1e-4, d_lr=1e-5, u_seed=3)
+        out = tr.train_step(lr, hr)
+        assert all(np.isfinite(float(v)) for v in out.values()), out
+        assert set(tr.last_grads["g"]) == set(gw) and set(tr.last_grads["d"]) == set(dw)
+        for n, (k, b) in gw.items():
+            assert tr.last_grads["g"][n][0].shape == k.shape and tr.last_grads["g"][n][1].shape == b.shape, n
+            assert tr.gw[n][0].shape == k.shape and np.isfinite(tr.gw[n][0]).all(), n
+        bucket = sum(a.size for side in ("g", "d") for pair in tr.last_grads[side].values() for a in pair)
+        assert bucket == 16930019 + 658305                       # what allreduce_mean_grads carries as one flat fp32 bucket (70.4 MB)
+        assert tuple(tr.last_dy.shape) == (16, 96, 96, 3)
+        runs.append((out, {n: tr.last_grads["g"][n][0].copy() for n in ("initial_conv", "rrdb_11_dense2_conv3", "final_conv2")},
+                     tr.gw["rrdb_22_dense3_conv5"][0].copy(), tr.dw["disc_conv1"][0].copy()))
+    assert runs[0][0] == runs[1][0]                               # deterministic reductions: the same losses ...
+    assert all(np.array_equal(runs[0][1][n], runs[1][1][n]) for n in runs[0][1]) and np.array_equal(runs[0][2], runs[1][2]) and np.array_equal(runs[0][3], runs[1][3])   # ... gradients, weights
+    # ---- the oracle at this depth, on two of the patches
+    tr = GT.ESRGANTrainer(ctx, gw, dw, vw, scale, nb, attention=True, g_lr=1e-4, d_lr=1e-5, u_seed=3)
+    u0 = {n: v.copy() for n, v in tr.u.items()}
+    out = tr.train_step(lr[:2], hr[:2])
+    dy = tr.last_dy.cpu().numpy().astype(np.float64)
+    ref = OT.esrgan_train_step_ref(gw, dw, u0, vw, lr[:2], hr[:2], scale, nb, attention=True, dy_override=dy)
+    for k, v in ref["losses"].items():
+        assert abs(out[k] - v) <= 5e-4 * max(1.0, abs(v)), (k, out[k], v)
+    for n in ("initial_conv", "rrdb_0_dense1_conv1", "rrdb_11_dense2_conv3", "rrdb_22_dense3_conv5", "trunk_conv", "upsample_1_conv", "final_conv2"):
+        e = rel_l2(tr.last_grads["g"][n][0], ref["g_grads"][n][0])
+        assert e <= 5e-4, (n, e)
+    for n, (rk, rb) in ref["d_grads"].items():
+        assert rel_l2(tr.last_grads["d"][n][0], rk) <= 5e-4, ("d", n)
+
+
 def test_esrgan_fit_wrapper(ctx, tmp_path):
     """ESRGAN.fit (ESRGAN_model.py:535-779): arrays in [0,1] -> shuffled batches in [-1,1] -> _train_step per batch; the returned
     record is the last epoch's; the first step of the first epoch is checked against the oracle's step on the same batch."""
