@@ -82,13 +82,12 @@ class EDSR(DeviceModelMixin):
         sr, metrics = P.patchwise_sr(self.model, lr, patch_size_lr, stride, self.scale_factor, chunk=256)
         return (sr.cpu().numpy() if is_np else sr), metrics
 
-    def save(self, directory, timestamp):
+    def save(self, directory, timestamp, fmt="npz"):
+        """EDSR_model.py:317-328; fmt="h5" writes Keras' weight layout (sr355.h5lite), "npz" this build's container."""
         if not self.trained:
             raise RuntimeError("Cannot save an untrained model.")
         if not directory:
             raise ValueError("Directory path must be provided.")
-        os.makedirs(directory, exist_ok=True)
-        path = os.path.join(directory, f"EDSR_x{self.scale_factor}_{timestamp}.npz")
-        self._save_npz(path)
+        path = self._save_weights(directory, f"EDSR_x{self.scale_factor}_{timestamp}", fmt)
         print(f"Model saved to {path}")
         return path

@@ -329,16 +329,18 @@ class ESRGAN(DeviceModelMixin):
                                            chunk=max(int(batch_size), 1), in_mul=2.0, in_add=-1.0, out_mul=0.5, out_add=0.5, timed=timed)
         return [sr.cpu().numpy() if c[1] else sr for sr, c in zip(srs, conv)], metrics
 
-    def save(self, directory, timestamp):
+    def save(self, directory, timestamp, fmt="npz"):
+        """ESRGAN_model.py:981-995 writes ESRGAN_generator_..h5 / ESRGAN_discriminator_..h5; fmt="h5" writes those names in Keras' weight
+        layout (sr355.h5lite), the default "npz" this build's own container."""
         if not self.trained:
             raise RuntimeError("Cannot save an untrained model.")
-        os.makedirs(directory, exist_ok=True)
-        generator_path = os.path.join(directory, f"ESRGAN_generator_x{self.scale_factor}_{timestamp}.npz")
-        self._save_npz(generator_path)
+        generator_path = self._save_weights(directory, f"ESRGAN_generator_x{self.scale_factor}_{timestamp}", fmt)
         print(f"Generator model saved to {generator_path}")
         if self.d_weights is not None:        # the stored (spectrally normalised) discriminator kernels, as model.save keeps them (:990-993)
-            from sr355.weights import save_npz
-            discriminator_path = os.path.join(directory, f"ESRGAN_discriminator_x{self.scale_factor}_{timestamp}.npz")
-            save_npz(discriminator_path, self.d_weights)
+            g, self.weights = self.weights, self.d_weights
+            try:
+                discriminator_path = self._save_weights(directory, f"ESRGAN_discriminator_x{self.scale_factor}_{timestamp}", fmt)
+            finally:
+                self.weights = g
             print(f"Discriminator model saved to {discriminator_path}")
         return generator_path

@@ -79,13 +79,13 @@ class SRCNNModel(DeviceModelMixin):
         sr, metrics = P.patchwise_sr(self.model, up, patch_size, stride, 1, chunk=256)
         return (sr.cpu().numpy() if is_np else sr), metrics
 
-    def save(self, directory, timestamp):
+    def save(self, directory, timestamp, fmt="npz"):
+        """SRCNN_model.py:249-260 writes SRCNN_<timestamp>.h5; fmt="h5" writes that name in Keras' weight layout (sr355.h5lite),
+        the default "npz" this build's own container.  Both load back through setup_model(from_pretrained=True)."""
         if not self._trained:
             raise RuntimeError("Cannot save an untrained model.")
         if not directory:
             raise ValueError("Directory path must be provided.")
-        os.makedirs(directory, exist_ok=True)
-        filepath = os.path.join(directory, f"SRCNN_{timestamp}.npz")
-        self._save_npz(filepath)
+        filepath = self._save_weights(directory, f"SRCNN_{timestamp}", fmt)
         print(f"Model saved to {filepath}")
         return filepath

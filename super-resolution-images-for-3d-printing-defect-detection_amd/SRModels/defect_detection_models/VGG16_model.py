@@ -158,11 +158,10 @@ class FineTunedVGG16(DeviceModelMixin):
         probs = self.model.predict(patches, batch_size=max(int(batch_size), 128))
         return P.majority_vote(probs.float().cpu().numpy())
 
-    def save(self, directory, timestamp):
+    def save(self, directory, timestamp, fmt="npz"):
+        """VGG16_model.py:272-283; fmt="h5" writes Keras' weight layout (sr355.h5lite), "npz" this build's container."""
         if not self.trained:
             raise RuntimeError("Cannot save an untrained model.")
-        os.makedirs(directory, exist_ok=True)
-        path = os.path.join(directory, f"VGG16_{timestamp}.npz")
-        self._save_npz(path)
+        path = self._save_weights(directory, f"VGG16_{timestamp}", fmt)
         print(f"Model saved to {path}")
         return path

@@ -29,6 +29,7 @@ struct AttnParams {
     const char* qkv; int64_t cs; int qoff, koff, voff;
     char* o; int64_t o_cs; int o_coff;
     int N;
+    const float* knorm;       // bf16 kernel: [B][ceil(N / 128)] largest Euclidean norm of a key in each 128-key group (attn_knorm_kernel)
 };
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
@@ -143,6 +144,29 @@ __global__ void __launch_bounds__(256, 2) attn_f32_kernel(AttnParams p) {
 constexpr int KT2 = 128;                       // keys per barrier
 constexpr int PITCH2 = KT2 * 2 + 8;            // bytes per V^T row: 66 dwords -> conflict-free ds_read_b64
 
+// Largest |k| of every 128-key group, one wave per group.  It lets the main kernel decide per GROUP, with scalar arithmetic only, that no
+// score of the group can outgrow the running max by more than the rescale-free bound (Cauchy-Schwarz: k.q <= |k| |q|), and then run tiles
+// that carry no max chain and no vote at all.
+__global__ void __launch_bounds__(64) attn_knorm_kernel(const bf16_t* qkv, int64_t cs, int koff, int N, int ngroups, float* out) {
+    const int g = blockIdx.x % ngroups, b = blockIdx.x / ngroups, lane = threadIdx.x;
+    const bf16_t* base = qkv + (int64_t)b * N * cs + koff;
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int key = g * 128 + t * 64 + lane;
+        if (key < N) {
+            const bf16x8 k = *reinterpret_cast<const bf16x8*>(base + (int64_t)key * cs);
+            float n2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) n2 += (float)k[e] * (float)k[e];
+            m = fmaxf(m, n2);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) out[(int64_t)b * ngroups + g] = sqrtf(m);
+}
+
 // __launch_bounds__(256, 3) (second argument: waves per SIMD): with a register ceiling <= 256 hipcc keeps MFMA results in VGPRs.
 // Without it the score tile and the output accumulator shared one AGPR block and every key tile paid 16 v_accvgpr_read + 32
 // v_accvgpr_write (ISA count), a third of the VALU slots of this VALU-bound loop.  3 waves/SIMD = 168 registers: the two query
@@ -167,6 +191,19 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
         qb[j] = z;                                     // h == 1 lanes: K-slots 8..15; slots 8, 9 will carry the running max
         if (h == 0) qb[j] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qc * cs + p.qoff);
     }
+    // |q| of the wave's largest query (wave-uniform): with attn_knorm's |k| it bounds every score of a key group
+    float qn2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) n2 += (float)qb[j][e] * (float)qb[j][e];
+        qn2 = fmaxf(qn2, n2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qn2 = fmaxf(qn2, __shfl_xor(qn2, o));
+    const float qmax = __builtin_amdgcn_readfirstlane(sqrtf(qn2)) * 1.0009765625f;      // a 2^-10 margin over the fp32 rounding of norms and products
+    const float* knorm = p.knorm + (int64_t)b * ((N + KT2 - 1) / KT2);
     f32x16 oacc[QB];
     // Row sums ride on the matrix core as well: a 16x16x32 MFMA with a 0/1 selector as A and the probability fragment (the PV
     // MFMA's B operand, reinterpreted) as B.  Lane (r, h) of the 32x32 layout is column r & 15, k-group 2h + (r >> 4) of the
@@ -287,19 +324,24 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
     // registers on the common path of every tile (24 v_mov_b64), and the loop also pays the vote; a loop made of fast tiles only
     // has neither (attention 241 -> ~185 ms per two bench steps).
     constexpr float GROW_OK = 40.f;    // 2^40 x 9216 keys x |v|: far inside fp32 for the sums and the bf16 probabilities
-    auto tile_fast = [&](const bf16x8 kf, const int sub) -> bool {
+    // guard (wave-uniform) = false: the group-level bound below already says that no score of this group exceeds the running max of any of
+    // the wave's queries by more than 2^GROW_OK -- the tile then carries no max chain and no vote: score MFMA, 16 exps, 8 converts, 3 MFMAs.
+    auto tile_fast = [&](const bf16x8 kf, const int sub, const bool guard) -> bool {
         f32x16 s[QB];
-        bool risky = false;
 #pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb[j], zero16, 0, 0, 0);
-            float m = fmaxf(fmaxf(s[j][0], s[j][1]), s[j][2]);
+        for (int j = 0; j < QB; ++j) s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qb[j], zero16, 0, 0, 0);
+        if (guard) {
+            bool risky = false;
 #pragma unroll
-            for (int i = 3; i + 1 < 16; i += 2) m = fmaxf(fmaxf(m, s[j][i]), s[j][i + 1]);
-            m = fmaxf(m, s[j][15]);
-            risky = risky || m > GROW_OK;
+            for (int j = 0; j < QB; ++j) {
+                float m = fmaxf(fmaxf(s[j][0], s[j][1]), s[j][2]);
+#pragma unroll
+                for (int i = 3; i + 1 < 16; i += 2) m = fmaxf(fmaxf(m, s[j][i]), s[j][i + 1]);
+                m = fmaxf(m, s[j][15]);
+                risky = risky || m > GROW_OK;
+            }
+            if (__any(risky)) return false;
         }
-        if (__any(risky)) return false;
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
 #pragma unroll
@@ -322,7 +364,19 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
         }
         return true;
     };
-    // V^T of KT2 keys into LDS, two keys per dword (every wave of the workgroup passes here once per key group, in either mode)
+    // smallest running max among the wave's queries (wave-uniform); refreshed after every group that ran the full logic
+    auto wave_min_m = [&]() {
+        float m = m_run[0];
+#pragma unroll
+        for (int j = 1; j < QB; ++j) m = fminf(m, m_run[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+        return __builtin_amdgcn_readfirstlane(m);
+    };
+    float mmin = 0.f;
+    // V^T of KT2 keys into LDS, two keys per dword (every wave of the workgroup passes here once per key group, in either mode).
+    // (Round 3 measured a double-buffered image with the rows requested a whole group ahead: no faster -- the loop is bound by vector
+    // issue, 16 v_exp_f32 + 8 converts + 5 MFMAs per 32 x 32 scores, not by this staging -- and eight more live registers.)
     auto stage_v = [&](const int k0) {
         __syncthreads();
 #pragma unroll
@@ -358,17 +412,23 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
         stage_v(k0);
         int sub = 0;
         bf16x8 kf = knext;
-        if (k0 != 0 && k0 + KT2 <= N) {
+        const bool full = k0 != 0 && k0 + KT2 <= N;
+        if (full) {
+            // group-level bound (scalar): every score k.q - m of this group is <= |k|max |q|max - min m; where it holds the tiles run unguarded
+            const bool guard = !(knorm[k0 / KT2] * qmax - mmin <= GROW_OK);
 #pragma unroll
             for (; sub < KT2 / 32; ++sub) {
                 kf = knext;
                 knext = load_k(k0 + sub * 32 + 32);          // next tile's keys fly under this tile's softmax
-                if (!tile_fast(kf, sub)) break;
+                if (!tile_fast(kf, sub, guard)) break;
             }
         } else {
             knext = load_k(k0 + 32);
         }
-        if (sub < KT2 / 32) slow_tiles(k0, sub, kf);
+        if (sub < KT2 / 32) {
+            slow_tiles(k0, sub, kf);
+            mmin = wave_min_m();
+        }
     }
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
@@ -394,7 +454,7 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
     const int esz = dtype_size(dtype);
     if ((cs * esz) % 16 || (qoff * esz) % 16 || (koff * esz) % 16 || (voff * esz) % 16 || (o_cs * esz) % 16 || (o_coff * esz) % 16)
         return ctx->fail(SR_ERR_INVALID, "attention: views must be 16-byte aligned");
-    AttnParams p{static_cast<const char*>(qkv), cs, qoff, koff, voff, static_cast<char*>(o), o_cs, o_coff, N};
+    AttnParams p{static_cast<const char*>(qkv), cs, qoff, koff, voff, static_cast<char*>(o), o_cs, o_coff, N, nullptr};
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)B);
     if (dtype != SR_DTYPE_BF16 && dtype != SR_DTYPE_F32) return ctx->fail(SR_ERR_INVALID, "attention: dtype must be f32 or bf16");
     const int rec = ctx->prof_open(dtype == SR_DTYPE_BF16 ? "attn<bf16>" : "attn<f32>", 2.0 * B * (double)N * N * 40.0,
@@ -402,8 +462,17 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
     if (dtype == SR_DTYPE_BF16) {
         // two 32-query blocks per wave (256 queries per workgroup): the blocks share the key fragment and give the
         // scheduler two independent softmax chains (measured 3 % faster than one block per wave)
-        const int64_t nwg = (int64_t)B * ((N + 255) / 256);
-        hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        static const int qb_env = [] { const char* e = getenv("SR355_ATTN_QB"); return e ? atoi(e) : 2; }();      // tuning switch: query blocks per wave
+        const int QBr = qb_env == 1 ? 1 : 2;
+        const int64_t nwg = (int64_t)B * ((N + 128 * QBr - 1) / (128 * QBr));
+        const int ngroups = (N + KT2 - 1) / KT2;
+        if (nwg >= (1ll << 31) || (int64_t)B * ngroups >= (1ll << 31)) { ctx->prof_close(rec, st); return ctx->fail(SR_ERR_INVALID, "attention: too many workgroups for one launch"); }
+        float* kn = static_cast<float*>(ctx->arena(ctx->attn_kn, sizeof(float) * (size_t)B * ngroups, st));
+        if (!kn) { ctx->prof_close(rec, st); return SR_ERR_OOM; }
+        p.knorm = kn;
+        hipLaunchKernelGGL(attn_knorm_kernel, dim3((unsigned)((int64_t)B * ngroups)), dim3(64), 0, st, reinterpret_cast<const bf16_t*>(qkv) + 0, cs, koff, N, ngroups, kn);
+        if (QBr == 1) hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, st, p);
     }
     else hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, st, p);
     ctx->prof_close(rec, st);

@@ -49,6 +49,7 @@ struct sr_ctx {
     int ensure_dyn_lds(const void* kernel, int bytes);
     void* tab_buf = nullptr; size_t tab_cap = 0;   // tap tables of sr_resize (stream-ordered reuse)
     struct Arena { void* p = nullptr; size_t cap = 0; };
+    Arena attn_kn;                // attention: per-key-group largest key norm (stream-ordered reuse)
     Arena dev_w, dev_b, dev_x;    // sr_conv2d_dev: packed weights / padded bias / padded input of the call in flight (stream-ordered reuse)
     void* arena(Arena& a, size_t bytes, hipStream_t st);   // grow-only; growing waits for `st` first
     void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)

@@ -10,20 +10,22 @@ from .weights import init_weights, load_npz, save_npz
 
 
 def load_pretrained(path):
-    """Keras `load_model(path)` stand-in.  `.npz` (this build's container) always; `.h5` only where h5py exists."""
+    """Keras `load_model(path)` stand-in (SRCNN_model.py:35, ESRGAN_model.py:143-149, VGG16_model.py:42).  `.npz` is this build's own
+    container; `.h5` is the reference's (`model.save`, SRCNN_model.py:249-260): read with h5py where it is installed, otherwise with the
+    NumPy reader in sr355.h5lite (contiguous, unfiltered datasets in old-style groups: what Keras / h5py write by default)."""
     if path is None or not os.path.isfile(path):
         raise FileNotFoundError(f"Pretrained model file not found at {path}")
-    if path.endswith(".h5"):
-        try:
-            import h5py  # noqa: F401
-        except ImportError as e:
-            raise ImportError("reading Keras .h5 checkpoints needs h5py, which is not installed; convert to .npz") from e
+    if path.endswith((".h5", ".hdf5", ".keras.h5")):
         return _load_h5(path)
     return load_npz(path)
 
 
 def _load_h5(path):
-    import h5py
+    try:
+        import h5py
+    except ImportError:
+        from .h5lite import load_keras_weights
+        return load_keras_weights(path)
     out = {}
     with h5py.File(path, "r") as f:
         g = f["model_weights"] if "model_weights" in f else f
@@ -34,7 +36,7 @@ def _load_h5(path):
                 slot = 0 if "kernel" in name.split("/")[-1] else 1
                 out.setdefault(layer, [None, None])[slot] = np.asarray(obj)
         g.visititems(visit)
-    return {n: (k, b) for n, (k, b) in out.items()}
+    return {n: (k, b if b is not None else np.zeros(k.shape[-1], np.float32)) for n, (k, b) in out.items()}
 
 
 class DeviceModelMixin:
@@ -58,6 +60,21 @@ class DeviceModelMixin:
 
     def _save_npz(self, path):
         save_npz(path, self.weights)
+
+    def _save_weights(self, directory, stem, fmt="npz"):
+        """`model.save(os.path.join(directory, stem + ".h5"))` in the reference (SRCNN_model.py:249-260).  fmt "npz" (default: this
+        build's container) or "h5" (Keras' weight layout, written by sr355.h5lite: readable by this package and by Keras' load_weights)."""
+        os.makedirs(directory, exist_ok=True)
+        if fmt == "h5":
+            from .h5lite import save_keras_weights
+            path = os.path.join(directory, stem + ".h5")
+            save_keras_weights(path, self.weights, model_name=stem)
+        elif fmt == "npz":
+            path = os.path.join(directory, stem + ".npz")
+            save_npz(path, self.weights)
+        else:
+            raise ValueError(f"fmt must be 'npz' or 'h5', not {fmt!r}")
+        return path
 
 
 def evaluate_sr(ctx, predict, X, Y, batch_size=32):

@@ -1,5 +1,7 @@
 """The reference-shaped classes (SRModels/*) end to end on the GPU: super_resolve_image / evaluate / classify /
 metrics against the oracle pipelines, plus the reference's guard exceptions."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -7,7 +9,7 @@ import torch
 from oracle import models as M
 from oracle import ops as O
 from sr355.synth import make_pairs
-from sr355.weights import bf16_rounded
+from sr355.weights import bf16_rounded, init_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -301,3 +303,33 @@ def test_streaming_pipeline_full_size_frame_properties(ctx):
     print(f"\n1080p frame: {stats['frames_per_s']:.2f} frames/s, {stats['sr_output_mpix_per_s']:.1f} SR MPix/s (first frame includes workspace allocation)")
     g.generator.release_workspace()
     c.model.release_workspace()
+
+
+def test_keras_h5_checkpoints_load_and_save(ctx, tmp_path):
+    """`setup_model(from_pretrained=True, pretrained_path=...h5)` (SRCNN_model.py:23-43) on the committed Keras-layout file
+    written by the genuine HDF5 library (tests/golden/srcnn_keras_layout.h5), and `save(..., fmt="h5")` -> the reference's file name, which
+    loads back to the same predictions (SRCNN_model.py:249-260).  ESRGAN's generator / discriminator pair the same way (:981-995, :143-149)."""
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    from SRModels.deep_learning_models.SRCNN_model import SRCNNModel
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "srcnn_keras_layout.h5")
+    w = init_weights(M.srcnn_layers(), seed=1000)
+    x = np.random.default_rng(5).uniform(0, 1, (2, 20, 24, 3)).astype(np.float32)
+    m = SRCNNModel()
+    m.setup_model(from_pretrained=True, pretrained_path=golden)
+    got = np.asarray(m.model.predict(x))
+    assert np.max(np.abs(got - M.srcnn_forward(x, w, dtype=np.float64))) <= 1e-5
+    path = m.save(str(tmp_path), "20260101", fmt="h5")
+    assert os.path.basename(path) == "SRCNN_20260101.h5"
+    m2 = SRCNNModel()
+    m2.setup_model(from_pretrained=True, pretrained_path=path)
+    assert np.array_equal(np.asarray(m2.model.predict(x)), got)
+    with pytest.raises(ValueError):
+        m.save(str(tmp_path), "x", fmt="pkl")
+    g = ESRGAN(compute_dtype="f32")
+    g.setup_model(scale_factor=2, growth_channels=8, num_rrdb_blocks=1)
+    g.trained = True
+    gp = g.save(str(tmp_path), "t1", fmt="h5")
+    assert os.path.basename(gp) == "ESRGAN_generator_x2_t1.h5"
+    g2 = ESRGAN(compute_dtype="f32")
+    g2.setup_model(scale_factor=2, from_trained=True, generator_pretrained_path=gp)
+    assert g2.num_rrdb_blocks == 1 and all(np.array_equal(g2.weights[n][0], g.weights[n][0]) for n in g.weights)
