@@ -198,6 +198,12 @@ int  sr_conv2d_dev(sr_ctx* ctx, const void* x, int B, int H, int W, int Cin, con
                    int rot, int act, float alpha, const void* skip1, float beta1, const void* skip2, float beta2, int clip01,
                    int d2s_r, void* y, void* stream);
 int  sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, float beta, void* out, int64_t n, void* stream);
+/* keras.optimizers.Adam's dense update (the optimiser of ESRGAN_model.py:176-195, SRCNN_model.py:55-60, EDSR_model.py:127-140) over one flat
+ * fp32 bucket of n parameters, in place on the device: g is first multiplied by grad_scale (1 / world size after a summing all-reduce; 1 leaves
+ * it alone), then m = b1 m + (1-b1) g, v = b2 v + (1-b2) g g, w -= lr_t m / (sqrt(v) + epsilon); lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) is the
+ * caller's (it knows the step count).  Each operation is rounded on its own: bit for bit NumPy's fp32 evaluation of the same expression. */
+int  sr_adam(sr_ctx* ctx, void* w, const void* g, void* m, void* v, int64_t n, float lr_t, float beta1, float one_minus_beta1, float beta2,
+             float one_minus_beta2, float epsilon, float grad_scale, void* stream);
 int  sr_space_to_depth(sr_ctx* ctx, const void* x, int B, int H, int W, int C, int r, void* y, void* stream);
 /* More halves of ESRGAN._train_step's backward pass (ESRGAN_model.py:475-533), fp32 device tensors:
  * sr_matmul: C[b] = alpha * op(A[b]) op(B[b]) (row-major, op = transpose when the flag is set) -- the MATERIALISED SelfAttention of the

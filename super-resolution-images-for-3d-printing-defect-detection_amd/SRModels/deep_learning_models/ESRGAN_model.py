@@ -118,7 +118,7 @@ class ESRGAN(DeviceModelMixin):
             self._ensure_loss_networks()
             self._trainer = ESRGANTrainer(self.ctx, self.weights, self.d_weights, self.vgg_weights, self.scale_factor,
                                           self.num_rrdb_blocks, attention=self.use_attention, g_lr=1e-4, d_lr=1e-5,
-                                          allreduce=getattr(self, "grad_allreduce", None))
+                                          allreduce=getattr(self, "grad_allreduce", None), allreduce_flat=getattr(self, "grad_allreduce_flat", None))
             self.g_optimizer, self.d_optimizer = self._trainer.g_opt, self._trainer.d_opt
         return self._trainer
 
@@ -128,8 +128,9 @@ class ESRGAN(DeviceModelMixin):
         initial weights and spectral-norm vectors are identical on every rank, so the replicas stay in step.  Call before fit()."""
         from sr355 import dist as D
         self.grad_allreduce = lambda grads: D.allreduce_mean_grads(grads, device=self.ctx.torch_device)
+        self.grad_allreduce_flat = D.allreduce_mean_flat          # the generator's bucket is reduced where it lies (RCCL on the device)
         if getattr(self, "_trainer", None) is not None:
-            self._trainer.allreduce = self.grad_allreduce
+            self._trainer.allreduce, self._trainer.allreduce_flat = self.grad_allreduce, self.grad_allreduce_flat
 
     def _sync_from_trainer(self):
         tr = self._trainer
@@ -194,7 +195,7 @@ class ESRGAN(DeviceModelMixin):
         preview = None                                      # (lr batch, already normalised?) fixed across epochs (:616-646)
 
         def generate_f32(lr_pm1):
-            t = Tape(self.ctx, tr.gw, wgrad=False)
+            t = tr.generator_tape(wgrad=False)          # multiplies with the trainer's device-resident parameters
             out = generator_forward(t, Var(self.ctx.to_device(np.asarray(lr_pm1, np.float32)), need=False), tr.scale, tr.nb, tr.att).v
             t.ops = []
             return out

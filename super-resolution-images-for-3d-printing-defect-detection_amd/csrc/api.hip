@@ -65,6 +65,14 @@ void* sr_ctx::scratch(size_t bytes) {
     return scratch_buf;
 }
 
+int sr_ctx::cu_count() {
+    if (num_cus <= 0) {
+        hipDeviceProp_t prop;
+        num_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return num_cus;
+}
+
 void* sr_ctx::arena(Arena& a, size_t bytes, hipStream_t st) {
     if (bytes <= a.cap) return a.p;
     if (a.p) { (void)hipStreamSynchronize(st); dfree(a.p); a.p = nullptr; a.cap = 0; }
@@ -1022,6 +1030,15 @@ int sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, f
     if (!ctx) return SR_ERR_INVALID;
     if (!a || !out) return ctx->fail(SR_ERR_INVALID, "null tensor");
     return eltwise_launch(ctx, op, static_cast<const float*>(a), static_cast<const float*>(b), alpha, beta, static_cast<float*>(out), n, static_cast<hipStream_t>(stream));
+}
+
+int sr_adam(sr_ctx* ctx, void* w, const void* g, void* m, void* v, int64_t n, float lr_t, float beta1, float one_minus_beta1, float beta2,
+            float one_minus_beta2, float epsilon, float grad_scale, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!w || !g || !m || !v) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    return adam_launch(ctx, static_cast<float*>(w), static_cast<const float*>(g), static_cast<float*>(m), static_cast<float*>(v), n, lr_t, beta1,
+                       one_minus_beta1, beta2, one_minus_beta2, epsilon, grad_scale, static_cast<hipStream_t>(stream));
 }
 
 int sr_space_to_depth(sr_ctx* ctx, const void* x, int B, int H, int W, int C, int r, void* y, void* stream) {

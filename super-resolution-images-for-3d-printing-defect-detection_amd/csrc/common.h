@@ -54,6 +54,7 @@ struct sr_ctx {
     void* arena(Arena& a, size_t bytes, hipStream_t st);   // grow-only; growing waits for `st` first
     void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
+    int cu_count();               // compute units of the device (queried once)
     int chain_mask = 3;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3 (sr_debug_set_fused; default both)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
@@ -180,6 +181,8 @@ int vgg_preproc_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, v
 int l1_launch(sr_ctx* ctx, const float* a, const float* b, int64_t n, float* out, hipStream_t st);
 int spectral_l1_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float* out, hipStream_t st);
 int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS, float* dw, float* db, hipStream_t st);
+int adam_launch(sr_ctx* ctx, float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float omb1, float b2, float omb2, float eps,
+                float gscale, hipStream_t st);
 int eltwise_launch(sr_ctx* ctx, int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n, hipStream_t st);
 int space_to_depth_launch(sr_ctx* ctx, const float* x, int B, int H, int W, int C, int r, float* y, hipStream_t st);
 int matmul_launch(sr_ctx* ctx, const float* A, const float* B, float* C, int batch, int M, int N, int K, int tA, int tB, float alpha, hipStream_t st);

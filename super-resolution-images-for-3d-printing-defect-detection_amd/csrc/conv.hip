@@ -26,6 +26,8 @@
 //
 // HBM traffic per launch (algorithmic): B*H*W*(Cin + Cout)*sizeof(T) (+ skips); FLOP
 // 2*B*H*W*KS^2*Cin*Cout.  DESIGN.md prices each layer against both roofs.
+#include <type_traits>
+
 #include "conv_common.h"
 
 #include <cstdio>
@@ -244,9 +246,8 @@ __global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
 
 constexpr int MT_DEFAULT = 3;   // 24 x 16 pixel tiles: 48/96/192-pixel patches tile exactly
 
-template <typename T, int KS, int KGPT, int NT>
-int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
-    constexpr int MT = MT_DEFAULT;
+template <typename T, int KS, int KGPT, int NT, int MT>
+int launch_wide_mt(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     constexpr int PH = 8 * MT + KS - 1, PW = 16 + KS - 1, CS = KGPT * 32 + 16;
     constexpr int lds = ((PH * PW * CS + 15) & ~15) + KS * KS * KGPT * NT * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -259,6 +260,18 @@ int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
+}
+
+template <typename T, int KS, int KGPT, int NT>
+int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
+    // Small fp32 problems (the training step's 16 x 24 x 24 batches: 9216 pixels) give the 24 x 16 tiling 32 workgroups per cout tile on
+    // 256 CUs -- a launch then takes as long as one workgroup's whole K loop (round 2: 146 us for 0.85 GFLOP).  8 x 16 tiles give three
+    // times the workgroups and a third of the serial work each.  (bf16 inference never gets here with so few pixels.)
+    if constexpr (std::is_same<T, float>::value) {
+        const int64_t wgs3 = (int64_t)((p0.W + 15) / 16) * ((p0.H + 8 * MT_DEFAULT - 1) / (8 * MT_DEFAULT)) * p0.B * nct;
+        if (wgs3 < 2 * ctx->cu_count()) return launch_wide_mt<T, KS, KGPT, NT, 1>(ctx, p0, nct, st);
+    }
+    return launch_wide_mt<T, KS, KGPT, NT, MT_DEFAULT>(ctx, p0, nct, st);
 }
 
 template <typename T, int KS, int NT>
@@ -482,7 +495,10 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
 
 // ---- device-side packing (fp32): one thread per packed element decodes its (tap, cin, cout) exactly as the host loops above
 __global__ void pack_weights_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int layout, int ntap, int Cin, int Cout,
-                                        int CinP, int NT, int nchunks, int KGPT, int rot) {
+                                        int CinP, int NT, int nchunks, int KGPT, int rot, const float* __restrict__ bias, float* __restrict__ bias_out, int CoutP) {
+    // the zero-padded bias rides along (block 0): one launch per conv use less than a separate pad kernel
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < CoutP; i += blockDim.x) bias_out[i] = (bias && i < Cout) ? bias[i] : 0.f;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         int tap, ci, co;
         if (layout == 0) {                        // few: [tap][CinP][4]
@@ -509,11 +525,6 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ src, float* __
             v = rot ? src[((int64_t)(ntap - 1 - tap) * Cout + co) * Cin + ci] : src[((int64_t)tap * Cin + ci) * Cout + co];
         dst[idx] = v;
     }
-}
-
-__global__ void pad_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int Cout, int CoutP) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < CoutP) out[i] = (b && i < Cout) ? b[i] : 0.f;
 }
 
 int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias, int KS, int Cin, int Cout, int rot, ConvWeights* out, hipStream_t st) {
@@ -558,8 +569,7 @@ int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias,
     if (!w.w || !w.bias) return SR_ERR_OOM;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_f32_kernel, dim3(blocks), dim3(256), 0, st, d_hwio, static_cast<float*>(w.w), n, layout, ntap, Cin, Cout, w.CinP,
-                       w.NT, w.nchunks, w.KGPT, rot);
-    hipLaunchKernelGGL(pad_bias_kernel, dim3((w.CoutP + 63) / 64), dim3(64), 0, st, d_bias, w.bias, Cout, w.CoutP);
+                       w.NT, w.nchunks, w.KGPT, rot, d_bias, w.bias, w.CoutP);
     SR_HIP(ctx, hipGetLastError());
     *out = w;
     return SR_OK;

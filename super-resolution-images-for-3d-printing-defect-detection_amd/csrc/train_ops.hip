@@ -31,19 +31,32 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    // the 4 waves interleave pixel pairs
-    for (int64_t p = p0 + 2 * wave; p < p1; p += 8) {
-        const int64_t pp = p + k;
-        float a = 0.f, bv = 0.f;
-        if (pp < p1) {
-            const int xq = (int)(pp % W);
-            const int64_t r = pp / W;
-            const int yq = (int)(r % H);
+    // The 4 waves interleave pixel pairs; a lane walks pixels pp = p0 + 2 wave + k, + 8, + 16, ...  Round 3: the pixel's (row, column) is
+    // carried along instead of being divided out of pp every time, and eight pixel pairs' operands are requested before the eight MFMAs that
+    // consume them (round 2: one dependent pair of loads in front of every MFMA -- a launch ran at the latency of 256 serial loads, 151 us
+    // for 0.2 GFLOP).  The MFMAs still run in pixel order, so the sums are bit for bit the ones of round 2.
+    constexpr int U = 8;
+    int64_t pp = p0 + 2 * wave + k;
+    int xq = (int)(pp % W);
+    int64_t r = pp / W;                     // image row counted through the batch
+    int yq = (int)(r % H);
+    for (int64_t pb = p0 + 2 * wave; pb < p1; pb += 8 * U) {
+        float a[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = pp < p1;
             const int sy = yq + ky - pad, sx = xq + kx - pad;
-            if (ci_ok && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) a = x[((r - yq + sy) * W + sx) * Cin + ci];
-            if (co_ok) bv = dy[pp * Cout + co];
+            const bool in = live && ci_ok && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+            const float av = x[in ? ((r - yq + sy) * W + sx) * Cin + ci : 0];
+            const float bw = dy[(live && co_ok) ? pp * Cout + co : 0];
+            a[u] = in ? av : 0.f;
+            bv[u] = (live && co_ok) ? bw : 0.f;
+            pp += 8;
+            xq += 8;
+            while (xq >= W) { xq -= W; ++r; if (++yq == H) yq = 0; }
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
     }
     // sum the 4 waves' tiles through LDS, fixed order
     __shared__ float red[4][32 * 32];
@@ -310,6 +323,30 @@ int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial);
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(Cout), dim3(256), 0, st, dy, P, Cout, db);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+// keras.optimizers.Adam (TF 2.10 optimizer_v2, dense update) over a flat fp32 bucket, in place:
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  w = w - lr_t m / (sqrt(v) + eps),  lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) from the host.
+// Every operation is rounded on its own (no fma contraction), in the order sr355.train.Adam's NumPy expression evaluates them, so the device
+// update is bit for bit the host one (tests/test_train_gpu.py compares the two on one bucket).
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr_t, float b1, float omb1, float b2, float omb2, float eps, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = gscale == 1.f ? g[i] : __fmul_rn(g[i], gscale);
+        const float mi = __fadd_rn(__fmul_rn(b1, m[i]), __fmul_rn(omb1, gi));
+        const float vi = __fadd_rn(__fmul_rn(b2, v[i]), __fmul_rn(__fmul_rn(omb2, gi), gi));
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = __fsub_rn(w[i], __fdiv_rn(__fmul_rn(lr_t, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
+    }
+}
+
+int adam_launch(sr_ctx* ctx, float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float omb1, float b2, float omb2, float eps,
+                float gscale, hipStream_t st) {
+    if (n <= 0) return ctx->fail(SR_ERR_INVALID, "adam: empty bucket");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_n(n)), dim3(256), 0, st, w, g, m, v, n, lr_t, b1, omb1, b2, omb2, eps, gscale);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }

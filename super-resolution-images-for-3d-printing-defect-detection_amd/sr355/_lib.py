@@ -66,6 +66,7 @@ SIGNATURES = {
     "sr_conv2d_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _vp, _f, _i, _i, _vp, _vp]),
     "sr_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sr_eltwise": (_i, [_vp, _i, _vp, _vp, _f, _f, _vp, _i64, _vp]),
+    "sr_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "sr_space_to_depth": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_spatial_op": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sr_matmul": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),

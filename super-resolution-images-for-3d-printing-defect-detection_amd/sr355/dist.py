@@ -91,6 +91,17 @@ def allreduce_mean_grads(grads, device=None):
     return out
 
 
+def allreduce_mean_flat(flat):
+    """Data-parallel training, the generator's gradients: ONE flat fp32 device bucket (67.7 MB at the default depth) -> its mean over the
+    ranks.  Under RCCL the bucket is reduced where it lies -- it never touches the host (round 2 staged it through NumPy both ways); under
+    gloo (CPU tests, the one-GPU rehearsal) a device tensor goes through the host."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return flat
+    _allreduce(flat, dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    return flat
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

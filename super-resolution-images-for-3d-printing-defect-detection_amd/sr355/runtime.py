@@ -259,6 +259,17 @@ class Context:
                                        a.numel(), self.stream()))
         return out
 
+    def adam_step(self, w, g, m, v, lr_t, beta_1=0.9, beta_2=0.999, epsilon=1e-7, grad_scale=1.0):
+        """In-place Keras-Adam update of the flat fp32 device bucket w with gradient g and moments m, v (sr_adam)."""
+        import numpy as np
+        for t, what in ((w, "adam w"), (g, "adam g"), (m, "adam m"), (v, "adam v")):
+            _check_tensor(self, t, what)
+            if t.dtype != torch.float32 or t.numel() != w.numel():
+                raise ValueError("adam_step: four fp32 tensors of one size")
+        f = lambda x: float(np.float32(x))
+        self.check(self.lib.sr_adam(self.h, w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), f(lr_t), f(beta_1), f(1.0 - beta_1),
+                                    f(beta_2), f(1.0 - beta_2), f(epsilon), f(grad_scale), self.stream()))
+
     def space_to_depth(self, x, r):
         """Inverse of tf.nn.depth_to_space (DCR): [B,H*r,W*r,C] -> [B,H,W,r*r*C]."""
         _check_tensor(self, x, "space_to_depth input")

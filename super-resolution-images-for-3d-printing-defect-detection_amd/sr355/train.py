@@ -75,6 +75,23 @@ class Adam:
         return out
 
 
+class DeviceAdam:
+    """The same optimiser with its state on the device: parameters, both moments and the gradient are flat fp32 buckets and one fused kernel
+    (sr_adam) updates them in place -- no parameter leaves the GPU between steps.  Bit for bit the update of `Adam.apply` on the same numbers
+    (the kernel rounds every operation separately, in NumPy's order)."""
+
+    def __init__(self, ctx, flat_weights, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        import torch
+        self.ctx, self.lr, self.b1, self.b2, self.eps = ctx, float(learning_rate), beta_1, beta_2, epsilon
+        self.t = 0
+        self.m, self.v = torch.zeros_like(flat_weights), torch.zeros_like(flat_weights)
+
+    def apply(self, flat_weights, flat_grads, grad_scale=1.0):
+        self.t += 1
+        lr_t = np.float32(self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t))
+        self.ctx.adam_step(flat_weights, flat_grads, self.m, self.v, lr_t, self.b1, self.b2, self.eps, grad_scale)
+
+
 # ---------------------------------------------------------------------------------------------------------------- graphs
 def srcnn_loss_and_grads(ctx, w, x, t):
     """SRCNN_model.py:48-53 + mean_squared_error.  x, t device fp32 [B,H,W,3].  -> (prediction, loss tensor [1], {layer: (dw, db)})."""

@@ -94,6 +94,11 @@ def _dp_worker(rank, world, port, q):
         _, _, g = OT.loss_and_grads(OT.srcnn_forward_t, w64, x[lo:hi], t[lo:hi])
         g = D.allreduce_mean_grads(g)
         w64 = opt.apply(w64, g)
+    # the generator's route (ESRGANTrainer.allreduce_flat): one flat fp32 bucket averaged in place
+    bucket = torch.full((1000,), float(rank + 1), dtype=torch.float32)
+    bucket[::7] = float(10 * (rank + 1))
+    out = D.allreduce_mean_flat(bucket)
+    assert out is bucket and float(bucket[1]) == 1.5 and float(bucket[0]) == 15.0 and float(bucket.sum()) == 1.5 * 857 + 15.0 * 143
     flat = torch.from_numpy(np.concatenate([np.asarray(a, np.float64).ravel() for n in sorted(w64) for a in w64[n]]))
     other = flat.clone()
     D.allreduce_max(other)
