@@ -252,6 +252,29 @@ def test_esrgan_train_step(ctx, cfg):
     assert tr.step == 1 and GT.staircase_lr(1e-4, 9999) == 1e-4 and GT.staircase_lr(1e-4, 10000) == 5e-5
 
 
+def test_device_adam_is_the_host_adam_bit_for_bit(ctx):
+    """sr_adam (the fused optimiser kernel of the GAN trainer's flat generator bucket) against sr355.train.Adam (the NumPy restatement of
+    keras.optimizers.Adam that SRCNN / EDSR fit and the discriminator use, itself checked against oracle/train.py's AdamRef): three steps on one
+    bucket, with a gradient scale as the data-parallel path applies it."""
+    rng = np.random.default_rng(12)
+    w0 = {"a": (rng.standard_normal((3, 3, 8, 16)).astype(np.float32), rng.standard_normal(16).astype(np.float32))}
+    host = T.Adam(w0, 1e-4, epsilon=1e-7)
+    flat = lambda d: np.concatenate([d["a"][0].ravel(), d["a"][1].ravel()])
+    wd = ctx.to_device(flat(w0))
+    dev = T.DeviceAdam(ctx, wd, 1e-4, epsilon=1e-7)
+    wh = w0
+    for step in range(3):
+        g = {"a": ((rng.standard_normal((3, 3, 8, 16)) * 10.0 ** rng.integers(-6, 2)).astype(np.float32), rng.standard_normal(16).astype(np.float32))}
+        scale = 1.0 if step < 2 else 0.5
+        wh = host.apply(wh, {"a": (g["a"][0] * np.float32(scale), g["a"][1] * np.float32(scale))})
+        dev.apply(wd, ctx.to_device(flat(g)), grad_scale=scale)
+        assert np.array_equal(wd.cpu().numpy(), flat(wh)), step
+    assert np.array_equal(dev.m.cpu().numpy(), np.concatenate([host.m["a"][0].ravel(), host.m["a"][1].ravel()]))
+    assert np.array_equal(dev.v.cpu().numpy(), np.concatenate([host.v["a"][0].ravel(), host.v["a"][1].ravel()]))
+    with pytest.raises(ValueError):
+        ctx.adam_step(wd, wd[:5].contiguous(), dev.m, dev.v, 1e-4)
+
+
 def test_esrgan_train_step_at_the_baseline_configuration(ctx):
     """BASELINE configs[3] at its stated size: x4, NB = 23, G = 32, both SelfAttention layers, 16 LR patches
     24x24 -> 96x96 per GPU, fp32 (ESRGAN_model.py:475-533 with the defaults of :108-112).  Shapes and the parameter bucket

@@ -26,12 +26,14 @@ struct P {
 };
 
 template <int MODE>
-__global__ void __launch_bounds__(MODE == 2 ? 768 : 512) k(P p) {
+__global__ void __launch_bounds__((MODE == 2 || MODE == 4) ? 768 : 512) k(P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // LDS: [0, 64 KiB) random operands, [64, 128 KiB) loader ring
     for (int u = tid; u < 4096; u += blockDim.x) reinterpret_cast<u32x4*>(smem)[u] = reinterpret_cast<const u32x4*>(p.rnd)[u];
+    unsigned* flags = reinterpret_cast<unsigned*>(smem + 140 * 1024);      // [0] granules published x 4 loaders, [1] granules finished x 8 compute waves
+    if (tid < 2) flags[tid] = tid == 0 ? 4u : 0u;                           // granule 0's operands are the random block already in LDS
     __syncthreads();
     unsigned long long t0 = 0, r0 = 0;
     if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -97,14 +99,22 @@ __global__ void __launch_bounds__(MODE == 2 ? 768 : 512) k(P p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (MODE == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+            if (MODE == 4) {
+                // done: this wave has finished reading granule `it`; then wait until the loaders have published granule it + 1
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int spins = 0;
+                while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4 * (it + 2) && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+            }
         }
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 18; ++j) sum += acc[j][0] + acc[j][3];
         if (sum == 12345.678f) p.sink[0] = sum;
-    } else if (MODE == 2 || MODE == 3) {
+    } else if (MODE == 2 || MODE == 3 || MODE == 4) {
         // loaders: per granule 29 pieces over 4 waves (7-8 each): ~11 from a private HBM stream (nt), ~18 from the shared random buffer (L2)
         const int lw = wave - (MODE == 3 ? 4 : 8);
+        (void)flags;
         const char* gh = p.hbm + (size_t)blockIdx.x * p.per_wg + (size_t)lw * (p.per_wg / 4) + lane * 16;
         const char* gl = p.rnd + lane * 16;
         unsigned slot = lw;
@@ -119,7 +129,15 @@ __global__ void __launch_bounds__(MODE == 2 ? 768 : 512) k(P p) {
                 else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gl + (((it * 7 + j) & 63) << 10)), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (MODE == 4) {
+                // publish (each loader counts once per granule: ready = 4 (it + 1) when all four have), then wait until every compute wave is
+                // done with granule it - 1 before the ring slot it used is overwritten two iterations on
+                if (lane == 0) __hip_atomic_fetch_add(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int spins = 0;
+                while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 8 * (it - 1) && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+            } else {
+                __builtin_amdgcn_s_barrier();
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -150,12 +168,13 @@ int main() {
     CHECK(hipEventCreate(&ea)); CHECK(hipEventCreate(&eb));
     const int lds = 150 * 1024;
     const char* names[] = {"bare MFMA, operands in registers", "MFMA + LDS operand reads (30 ds_read_b128 per 54 MFMAs)", "MFMA + LDS reads + 29 KiB of LDS-DMA per granule + one barrier per granule",
-                           "4 compute waves (one per SIMD) x two rows: 33 reads per 108 MFMAs, + LDS-DMA + barrier per granule"};
-    for (int mode = 0; mode < 4; ++mode) {
-        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : k<3>;
+                           "4 compute waves (one per SIMD) x two rows: 33 reads per 108 MFMAs, + LDS-DMA + barrier per granule",
+                           "mode 2 with the per-granule barrier replaced by a ready / done handshake through LDS counters"};
+    for (int mode = 0; mode < 5; ++mode) {
+        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : mode == 3 ? k<3> : k<4>;
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         P p{rnd, hbm, per_wg, stamps, sink, 20000};
-        const int threads = mode == 2 ? 768 : 512;      // mode 3: 4 compute + 4 loader waves
+        const int threads = (mode == 2 || mode == 4) ? 768 : 512;      // mode 3: 4 compute + 4 loader waves
         float ms = 0.f, total = 0.f;
         int n = 0;
         while (total < 2500.f && n < 400) {             // ~2.5 s of back-to-back launches, the last one is the measurement
