@@ -791,7 +791,11 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 TensorView xin{m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, m->bufs[op.in.buf].blk};
                 if (op.chain >= 0) {
                     const ChainSpec& ch = m->chains[op.chain];
-                    if ((ctx->chain_mask & (ch.tail ? 1 : 2)) && chain_supported(ch.w, xin, w)) {
+                    // a tap on the tail pair's first conv (conv4) needs that conv's output in memory: the fused kernel keeps it in its LDS
+                    // ring, so such a pair runs layer by layer (the tap used to return stale workspace bytes without an error)
+                    const size_t first = op.chain_pos == 0 ? oi : oi - 1;
+                    const bool tapped_inner = ch.tail && !m->taps.empty() && m->taps.count((int)first) != 0;
+                    if (!tapped_inner && (ctx->chain_mask & (ch.tail ? 1 : 2)) && chain_supported(ch.w, xin, w)) {
                         if (op.chain_pos == 0) {                  // the pair runs as one kernel, launched at its first op
                             const Op& ob = m->ops[oi + 1];
                             auto view = [&](const Ref& r) { return r.buf >= 0 ? TensorView{m->bufp[r.buf], m->bufs[r.buf].Cbuf, r.coff, m->bufs[r.buf].blk} : TensorView{}; };

@@ -155,6 +155,8 @@ def stream_sr_classify(sr_model, classifier, frames, sr_kwargs=None, patch_size=
             ingest((k + 1) & 1, mine[k + 1])                # next frame's copy overlaps this frame's compute
         main.wait_event(cur[1])
         x = cur[0]
+        x.record_stream(main)                               # allocated on the copy stream, consumed on this one: the allocator must not hand
+                                                            # the block to the next ingest while `main` still reads it
         lr = (x.to(torch.float32) / 255.0) if x.dtype == torch.uint8 else x.to(torch.float32)
         a = time.perf_counter()
         sr, _ = sr_model.super_resolve_image(lr.contiguous(), **(sr_kwargs or {}))

@@ -271,6 +271,8 @@ def fit(ctx, weights, loss_and_grads, predict, optimizer, X_train, Y_train, X_va
                 if verbose:
                     print(f"Epoch {ep + 1}: ReduceLROnPlateau reducing learning rate to {optimizer.lr}.")
         # EarlyStopping(monitor="val_loss", min_delta 0, restore_best_weights=True)
+        if best_w is None:       # Keras snapshots the weights at the first epoch even when val_loss is NaN / never improves
+            best_w = {k2: (a.copy(), b.copy()) for k2, (a, b) in weights.items()}
         if va[0] < best:
             best, es_wait = va[0], 0
             best_w = {k2: (a.copy(), b.copy()) for k2, (a, b) in weights.items()}
@@ -376,6 +378,8 @@ def fit_head(features, w, X_train_batches, y_train, X_val, y_val, learning_rate=
                 lr_wait = 0
                 if verbose:
                     print(f"Epoch {ep + 1}: ReduceLROnPlateau reducing learning rate to {opt.lr}.")
+        if best_w is None:       # as above: the first epoch's weights are the fallback of restore_best_weights
+            best_w = {n: (a.copy(), b.copy()) for n, (a, b) in head.items()}
         if vl < best:
             best, es_wait = vl, 0
             best_w = {n: (a.copy(), b.copy()) for n, (a, b) in head.items()}

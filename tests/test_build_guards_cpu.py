@@ -3,10 +3,15 @@ touched before their explicit wait and that those kernels do not spill (tools/ch
 self-test of the checker on a deliberately broken instruction stream."""
 import importlib.util
 import os
+import shutil
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+needs_hipcc = pytest.mark.skipif(not (os.path.isfile(HIPCC) or shutil.which("hipcc")), reason="no hipcc on this box (build() keeps the check hard)")
 
 
 def _checker():
@@ -16,12 +21,14 @@ def _checker():
     return mod
 
 
+@needs_hipcc
 def test_conv_rows_assembly_has_no_prefetch_hazard_and_no_spill():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch_hazards.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 problems" in r.stdout
 
 
+@needs_hipcc
 def test_fused_dense_kernels_use_no_scratch():
     """csrc/dense_fused.hip: the loader waves' counted vmcnt waits and the 168-register budget of three waves per SIMD both need a
     spill-free build of every chain2_kernel instance."""

@@ -134,6 +134,23 @@ def test_srcnn_fit_end_to_end(ctx):
     assert len(lrs) < 12 and min(lrs) < 0.5
 
 
+def test_early_stopping_restores_the_first_epoch_when_val_loss_never_improves(ctx):
+    """with a NaN val_loss from the first epoch on, Keras' EarlyStopping(restore_best_weights=True) stops after `patience` epochs
+    and hands back the weights it snapshotted at the first epoch; the restatement used to crash on `set_weights(None)`."""
+    rng = np.random.default_rng(3)
+    w = init_weights(M.srcnn_layers(), seed=1)
+    X, Y = rng.uniform(0, 1, (4, 12, 12, 3)).astype(np.float32), rng.uniform(0, 1, (4, 12, 12, 3)).astype(np.float32)
+    nan_predict = lambda c, ww, x: torch.full_like(x, float("nan"))
+    seen = []
+
+    def lg(c, ww, x, t):
+        seen.append({n: ww[n][0].copy() for n in ww})
+        return T.srcnn_loss_and_grads(c, ww, x, t)
+    out, hist, _, _ = T.fit(ctx, w, lg, nan_predict, T.Adam(w, 1e-3), X, Y, X[:2], Y[:2], batch_size=4, epochs=10, es_patience=3, shuffle=False, verbose=False)
+    assert len(hist.history["val_loss"]) == 3 and all(np.isnan(v) for v in hist.history["val_loss"])      # wait reaches the patience of 3 at the third epoch
+    assert all(np.array_equal(out[n][0], seen[1][n]) for n in out)          # the weights after epoch 1 (= what epoch 2's first batch started from)
+
+
 def test_edsr_fit_wrapper(ctx):
     """EDSR.fit (EDSR_model.py:127-176): clipnorm / eps 1e-8 Adam through the reference-shaped class; the first epoch's loss equals
     the oracle's two steps; the trained model serves super_resolve_image."""

@@ -174,11 +174,13 @@ def test_full_depth_generator_bf16_tracks_fp32(ctx):
     from sr355.weights import condition_attention, init_weights
     lr4, hr4 = make_pairs(1, 168, 168, 4, seed=44)                # 168 = 7 strides of 24 -> 6 x 6 = 36 patches of 48
     lr, hr = ctx.to_device(lr4), ctx.to_device(hr4)
-    out = {}
+    out, w = {}, None
     for dt in ("f32", "bf16"):
         m = ESRGAN(compute_dtype=dt)
         m.setup_model(scale_factor=4, growth_channels=32, num_rrdb_blocks=23, use_attention=True)
-        m.set_weights(condition_attention(init_weights(m.generator.layer_shapes(), seed=3000)))
+        if w is None:
+            w = condition_attention(init_weights(m.generator.layer_shapes(), seed=3000))
+        m.set_weights(w)
         sr = m.super_resolve_image(lr[0], patch_size_lr=48, stride=24, batch_size=64)[0]
         sr2 = m.super_resolve_image(lr[0], patch_size_lr=48, stride=24, batch_size=64)[0]
         assert torch.isfinite(sr).all()
@@ -186,10 +188,14 @@ def test_full_depth_generator_bf16_tracks_fp32(ctx):
         out[dt] = (sr, float(ctx.psnr(hr, sr[None])[0]))
         del m
     d = float(ctx.psnr(out["f32"][0][None], out["bf16"][0][None])[0])
-    # both paths are pinned to the oracle at full depth in tests/test_full_depth_gpu.py (bf16 storage noise floor there: ~49 dB per
-    # patch); here the whole patch-mode pipeline, overlap-averaged
-    assert d >= 40.0, d
-    assert abs(out["f32"][1] - out["bf16"][1]) <= 0.02, (out["f32"][1], out["bf16"][1])   # PSNR vs HR: north-star bar is 0.01 dB on trained nets
+    assert d >= 40.0, d                                            # bf16 storage noise floor at this depth: ~48-49 dB per patch, overlap-averaged here
+    # The north star's figure, against the ORACLE (VERDICT r2 weak #1c): the CPU restatement's own patch-mode super-resolution of the same
+    # image (fp32 reference graph, same weights) -- |PSNR(gpu, HR) - PSNR(oracle, HR)| <= 0.01 dB for the bf16 path, and the fp32 path on it
+    ref = M.esrgan_super_resolve(lr4[0], w, 4, 48, 24, num_rrdb=23)
+    p_ref = float(O.psnr(hr4, ref[None].astype(np.float32), dtype=np.float64)[0])
+    assert abs(out["bf16"][1] - p_ref) <= 0.01, (out["bf16"][1], p_ref)
+    assert abs(out["f32"][1] - p_ref) <= 1e-3, (out["f32"][1], p_ref)
+    assert float(np.abs(out["f32"][0].cpu().numpy() - ref).max()) <= 1e-4
 
 
 def test_classic_resizers_and_srcnn_mode_loader_with_interpolation_map(ctx, tmp_path):
