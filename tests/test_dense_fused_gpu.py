@@ -114,6 +114,7 @@ def test_fused_tail_exact_integers(fused_ctx):
     for c in (1, 2, 3):
         feats.append(OO.conv2d(np.concatenate(feats, axis=-1), *w[f"rrdb_0_dense1_conv{c}"], act="relu", dtype=np.float64))
     assert np.abs(feats[2]).max() < 256 and np.array_equal(feats[2], np.round(feats[2]))
-    for n, ref in (("rrdb_0_dense1_conv2", feats[2]), ("rrdb_0_dense1_conv3", feats[3])):
+    # (conv3's exact integer sums may exceed 2^8: the device stores them rounded to bf16 once, and so does the reference value here)
+    for n, ref in (("rrdb_0_dense1_conv2", feats[2]), ("rrdb_0_dense1_conv3", round_to_bf16(feats[3].astype(np.float32)).astype(np.float64))):
         assert np.array_equal(t1[n].float().cpu().numpy().astype(np.float64), ref), n
         assert np.array_equal(t0[n].float().cpu().numpy().astype(np.float64), ref), n

@@ -100,3 +100,30 @@ def test_generator_loss_and_evaluate_avg_g_loss(ctx):
     assert abs(ev["avg_g_loss"] - 0.5 * (r1 + r2)) <= 1e-4 * max(1.0, abs(r1))      # mean of per-batch means (Appendix C.8)
     with pytest.raises(ValueError):                       # fit exists now (tests/test_train_gpu.py); without data it raises as the reference does
         m.fit()
+
+
+def test_spectral_loss_kernels_follow_the_image_width_on_one_context(ctx):
+    """the spectral-loss kernels size their LDS by the image width (56 / 80 bytes per pixel).  The dynamic-LDS attribute of
+    a kernel used to be set once, at the first width above 48 KiB, and a later wider image failed with an opaque HIP error.  700 then 1500
+    pixels on the same context, forward and backward, against the oracle; widths that cannot fit a CU's 160 KiB are refused by name."""
+    rng = np.random.default_rng(8)
+    for W in (700, 1500, 900):                                   # 1500 raises both attributes; 900 afterwards must still work
+        a = rng.uniform(-1, 1, (1, 2, W, 3)).astype(np.float32)
+        b = rng.uniform(-1, 1, (1, 2, W, 3)).astype(np.float32)
+        ad, bd = ctx.to_device(a), ctx.to_device(b)
+        ref = O.spectral_loss(a, b)
+        got = float(ctx.spectral_l1(ad, bd).item())
+        assert abs(got - ref) <= 5e-5 * max(1.0, ref), (W, got, ref)
+        g = ctx.spectral_l1_bwd(ad, bd, 1.0)
+        assert tuple(g.shape) == a.shape and bool(torch.isfinite(g).all())
+        eps = 1e-3                                               # directional derivative against the oracle's finite difference
+        d = rng.standard_normal(a.shape).astype(np.float32)
+        fd = (O.spectral_loss(a + eps * d, b) - O.spectral_loss(a - eps * d, b)) / (2 * eps)
+        dd = float((g.cpu().numpy().astype(np.float64) * d).sum())
+        assert abs(dd - fd) <= 0.05 * abs(fd) + 1e-6, (W, dd, fd)
+    z = ctx.to_device(np.zeros((1, 1, 3000, 3), np.float32))
+    with pytest.raises(ValueError, match="exceeds"):
+        ctx.spectral_l1(z, z)
+    z2 = ctx.to_device(np.zeros((1, 1, 2100, 3), np.float32))
+    with pytest.raises(ValueError, match="exceeds"):
+        ctx.spectral_l1_bwd(z2, z2, 1.0)
