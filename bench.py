@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--raw-glorot", action="store_true",
                     help="round 1's weights: glorot without conditioning the attention logits (sr355.weights.condition_attention)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-rows", action="store_true", help="skip the other BASELINE rows (cfg3 training step, cfg4 streaming) that the N = 1 line carries beside the headline")
     ap.add_argument("--fused", type=int, default=3,
                     help="dense-block conv pairs run as one fused kernel: bit 0 conv4+conv5, bit 1 conv2+conv3 (0 = layer by layer, for A/B runs)")
     args = ap.parse_args()
@@ -372,6 +373,22 @@ def main():
             line["cpu_baseline"] = cpu_baseline(weights, lr4[0], keep=kept)
         if world == 1 and not args.no_parity and not args.no_attention:
             line["parity"] = parity_object(ctx, model, weights, lr4[0], hr4[0], kept.get("fp32_reference_graph"))
+        if world == 1 and not args.no_rows and not args.no_attention:
+            # BASELINE configs[3] and configs[4] beside the headline, outside its timed region (~25 s): so that the driver's record carries them.
+            # A failure here must not cost the headline line.
+            from sr355 import bench_rows as BR
+            rows = {}
+            for name, fn in (("cfg4_streaming_1080p", lambda: BR.cfg4_streaming(ctx, 3, generator=model)), ("cfg3_train_step", lambda: BR.cfg3_train_step(ctx, 3, 16))):
+                try:
+                    r = fn()
+                    r.pop("wall_s", None)
+                    rows[name] = r
+                except Exception as e:      # noqa: BLE001 -- reported in the line, the headline stands
+                    rows[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                if name == "cfg4_streaming_1080p":
+                    for m_ in models:
+                        m_.generator.release_workspace()     # the 3600-patch frames grew nothing beyond the 7056-patch step, but the trainer wants room
+            line["rows"] = rows
         print(json.dumps(line), flush=True)
     if world > 1:
         D.shutdown()
