@@ -23,12 +23,15 @@
 //     the whole kernel and put them into the slots with ds_write_b128); one s_barrier per granule (54 MFMAs per compute wave);
 //   * output rows leave through an LDS transposition (whole cache lines instead of 64 16-byte fragments per store instruction).
 // LDS: tail 2 x 33 + 30 + 3 x 18 KiB = 150 KiB, pairs 3 x 33 + 30 + 2 x 12 = 153 KiB -> one workgroup per CU, three waves per SIMD.
-// What bounds the kernels is the CU's vector-memory path (~16-21 B/clk in, ~12 B/clk out): DESIGN.md 3.3 has the measurements.
+// What bounds the kernels (round 3): not the CU's memory port -- it delivers 59 B/clk from L2 and the loaders now issue a
+// granule's pieces in ~0.5 k cycles -- but what this chip sustains for the loop's operand traffic: a skeleton of nothing but these MFMAs,
+// LDS reads, DMA volume and one barrier per granule reaches 1.37-1.41 PFLOP/s at 1.75 GHz (tools/micro/mfma_ceiling.hip); the tail runs at
+// 1.265.
 //
-// Epilogues: layer 0 = bias + ReLU -> bf16 -> LDS ring (+ global when a later kernel needs it); layer 1 = either the same
-// (growth conv) or the block's tail  alpha*(conv5 + b) + x [+ rrdb_in]  with x folded in from the staged chunk (the same
-// "skip from LDS" identity as conv_rows.hip), rrdb_in folded in during the ring granules, written to channels [0,64) of the next
-// block's buffer.
+// Epilogues: accumulators start at the bias; layer 0 = ReLU -> bf16 -> LDS ring (+ global when a later kernel needs it); layer 1 = either
+// the same (growth conv) or the block's tail  alpha*(conv5 + b) + x [+ rrdb_in]  with both skips joining the accumulators on the matrix core
+// as scaled-identity taps (x from the staged centre row, rrdb_in from two LDS-DMA'd pieces per ring granule), written to channels [0,64) of
+// the next block's buffer.
 #include <stdlib.h>
 #include <string.h>
 
@@ -121,17 +124,15 @@ constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + 
 // MODE 0: both layers are growth convs (ReLU) whose outputs go to chunks EXT and EXT+1 of the source buffer.
 // MODE 1: layer 0 is a growth conv kept on chip only, layer 1 is the block tail (NB1 = 4).
 //
-// Roles.  Issuing an LDS-DMA instruction holds the issuing wave for ~200-300 cycles here and all waves of a CU share one path from
-// L2 into LDS (in-kernel stamps, tools/probe_chain.py: ~40-50 cycles of that path per 1 KiB piece whoever issues it -- 4, 6 or 8
-// loader waves, or the compute waves themselves; s_setprio on the loaders changes nothing).  With every wave issuing its share
-// behind the barrier (first version) a granule spent 1.0-1.3 k cycles issuing and 1.7-2.1 k multiplying, one after the other.  So
-// the DMA stream belongs to four loader waves that do nothing else, running two granules ahead (three weight slots, counted
-// vmcnt): barrier -> issue -> wait for the previous iteration's pieces -> barrier; the eight compute waves go barrier -> MFMAs ->
-// barrier and touch vector memory only in the epilogues.  Measured and not kept: 6 / 8 loaders (same port time, compute waves
-// slower at 4 waves per SIMD and 128 registers), compute waves issuing 16 of a granule's 18 weight pieces (-10 %: everybody queues
-// on the port right after the barrier).  That path bounds the kernel (a piece from L2 ~47 cycles, from HBM ~130, the same with the MFMA
-// bodies skipped and with 8 or 252 workgroups on the chip), so everything since has been about moving fewer bytes through it: resident
-// weights in the loaders' spare registers, whole-line stores, an even number of pieces per iteration (below).
+// Roles.  Four loader waves own the whole DMA stream and run two granules ahead (three weight slots, counted vmcnt): barrier -> issue ->
+// wait for what the next barrier publishes -> barrier; the eight compute waves go barrier -> MFMAs -> barrier and touch vector memory only
+// in the epilogues (and for the RRDB skip's two pieces per ring granule).  Round 2 read its stamps (200-300 cycles per DMA issue, the same
+// with the MFMA bodies skipped) as a limit of the CU's L2 -> LDS path; round 3 measured that path alone (tools/micro/port_probe.hip:
+// 17 cycles per 1 KiB piece from L2 with four loaders) and found the loaders' own ~45 scalar instructions per piece instead -- see the
+// loader section below.  Measured in round 2 and not kept: 6 / 8 loaders (compute waves slower at 4 waves per SIMD and 128 registers),
+// compute waves issuing the weight pieces themselves (-10 %).  The loaders also keep part (growth pairs: all) of the weights in their spare
+// registers and write them into the slots with ds_write_b128: fewer L2 reads, and whole-line output stores through an LDS transposition
+// (DESIGN.md 3.3 items 2 and 4 stand).
 template <int EXT, int NB0, int NB1, int MODE, bool HAS_O, bool STAMP>
 __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4) chain2_kernel(ChainParams p) {
     using L = ChainLds<NB0, NB1, MODE>;
