@@ -49,7 +49,7 @@ struct ChainParams {
     const float* bias;                 // [16*NB0 | 16*NB1] fp32
     const char* zero;                  // ZERO_PAGE_BYTES of zeros: DMA source of separator / out-of-stream rows (same chunk offsets as real rows)
     int B, H;
-    int imgs_per_wg; unsigned magic;   // g / (H+1) == umulhi(g, magic) for every stream row index that occurs
+    int rows_per_wg; unsigned magic;   // stream rows (separators included) a workgroup owns; g / (H+1) == umulhi(g, magic) for every stream row index that occurs
     float alpha, xscale, oscale;       // MODE 1: out = alpha * (acc + bias + xscale * x + oscale * so); xscale = beta_x / alpha, oscale = beta_o / alpha, both exact in bf16
     int dbg_flags;                     // diagnostic builds only (env SR355_CHAIN_DBG_FLAGS): 1 = drop the tail's output stores, 2 = skip the external granules' MFMA bodies (timing experiments; results are wrong)
     unsigned long long* dbg;           // diagnostic builds only (sr_debug_set_chain_stamp_buffer): s_memtime stamps, [wg < 64][wave 0 / 5 / 8 / 11][granule < 64][4]
@@ -151,10 +151,16 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, Hp1 = H + 1;
-    const int img0 = blockIdx.x * p.imgs_per_wg;
-    const int nimg = min(p.imgs_per_wg, p.B - img0);
-    if (nimg <= 0) return;                             // whole workgroup (uniform)
-    const int N = nimg * Hp1;                          // stream rows, separators included
+    // Round 3: a workgroup owns a contiguous range [R0, R1) of the GLOBAL stream of rows (all images, a zero separator row after each), not a
+    // whole number of images: 882 patches on 256 CUs used to mean four images for 221 workgroups and none for 35 (what a rank sees at N = 8).
+    // The range may start and end inside an image, so the local stream begins one row early (layer 0 recomputes row R0 - 1 for layer 1's
+    // first own row) and ends one row late (layer 0's row R1 for layer 1's last); those two rows are computed, never stored -- the
+    // neighbouring workgroups own and store them, with the same values.
+    const int T = p.B * Hp1;                           // global stream rows
+    const int R0 = blockIdx.x * p.rows_per_wg, R1 = min(T, R0 + p.rows_per_wg);
+    if (R0 >= R1) return;                              // whole workgroup (uniform)
+    const int Rs = R0 - 1;                             // global row of local stream row 0
+    const int N = R1 - Rs + 1;                         // local stream rows layer 0 walks
     const int nsteps = (N + 1 + 7) >> 3;               // layer 1 lags one row
 
     // ---- one-time LDS state: the ring starts as zeros (rows above the first image), biases parked for the epilogues
@@ -164,12 +170,14 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    auto row_of = [&](int g, int& img, int& y) -> bool {          // stream row -> (image, row); false: separator / outside the stream
-        if (g < 0 || g >= N) return false;
-        img = (int)__umulhi((unsigned)g, p.magic);
-        y = g - img * Hp1;
+    auto row_of = [&](int g, int& img, int& y) -> bool {          // LOCAL stream row -> (image, row); false: separator / outside the stream
+        const int gg = Rs + g;                                     // (local rows -2, -1 and those past N are real rows of the neighbours' ranges: the warm-up row needs them)
+        if (gg < 0 || gg >= T) return false;
+        img = (int)__umulhi((unsigned)gg, p.magic);
+        y = gg - img * Hp1;
         return y < H;
     };
+    auto own = [&](int g) { return Rs + g >= R0 && Rs + g < R1; };    // rows this workgroup stores
     int G = 0;
     auto dma = [&](const char* src, char* dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -200,7 +208,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             auto row_base = [&](int s2, int j) -> const char* {
                 int img, y;
                 const bool real = row_of(8 * s2 - 2 + j, img, y);
-                return real ? p.in + ((int64_t)(img0 + img) * H + y) * p.in_nch * ROWB : p.zero;
+                return real ? p.in + ((int64_t)img * H + y) * p.in_nch * ROWB : p.zero;
             };
             // rows of a chunk this loader requests in the chunk's granule kx: {LW, LW + 4} | {8 + LW} (LW < 3) | {}
             using Plan = LoaderPlan<EXT, NB0, NB1, MODE, LW>;
@@ -531,7 +539,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
             int img, y;
             const bool real = row_of(g0, img, y);
             char* wrow = win + (g0 % WINR) * ROWB;
-            char* grow = real && MODE == 0 ? const_cast<char*>(p.in) + (((int64_t)(img0 + img) * H + y) * p.in_nch + EXT) * ROWB : nullptr;
+            char* grow = real && own(g0) && MODE == 0 ? const_cast<char*>(p.in) + (((int64_t)img * H + y) * p.in_nch + EXT) * ROWB : nullptr;
 #pragma unroll
             for (int cg = 0; cg < 3; ++cg) {
                 f32x4 v[NB0];
@@ -565,7 +573,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
         const char* sob = nullptr;
         if (MODE == 1 && HAS_O) {
             int img, y;
-            if (row_of(8 * s + wave - 1, img, y)) sob = p.so + ((int64_t)(img0 + img) * H + y) * p.so_nch * ROWB;
+            if (row_of(8 * s + wave - 1, img, y) && own(8 * s + wave - 1)) sob = p.so + ((int64_t)img * H + y) * p.so_nch * ROWB;
         }
         auto so_fetch = [&](int cg) {
             if (MODE == 1 && HAS_O && sob) {
@@ -608,9 +616,9 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
         // ---- layer 1 epilogue (row 8s+w-1): ReLU | * alpha -> bf16 -> transposition slot -> whole-line stores
         {
             int img, y;
-            const bool real = row_of(8 * s + wave - 1, img, y);
+            const bool real = row_of(8 * s + wave - 1, img, y) && own(8 * s + wave - 1);
             if (real && !(STAMP && (p.dbg_flags & 1))) {
-                const int64_t rowi = (int64_t)(img0 + img) * H + y;
+                const int64_t rowi = (int64_t)img * H + y;
                 char* const grow = MODE == 0 ? const_cast<char*>(p.in) + (rowi * p.in_nch + EXT + 1) * ROWB : p.out + rowi * p.out_nch * ROWB;
                 const float alpha = p.alpha;
                 int t_a, t_line;
@@ -749,10 +757,16 @@ int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H
     p.so = static_cast<const char*>(skip_o.p); p.so_nch = (int)(skip_o.cs / 32);
     p.w = static_cast<const char*>(w.w); p.bias = w.bias; p.zero = static_cast<const char*>(ctx->zero_page);
     p.B = B; p.H = H;
-    p.imgs_per_wg = (B + ncu - 1) / ncu;
-    const int nwg = (B + p.imgs_per_wg - 1) / p.imgs_per_wg;
-    p.magic = (unsigned)(((1ull << 32) + (unsigned)H) / (unsigned)(H + 1));                 // ceil(2^32 / (H+1)): exact quotient for g < 2^32 / (H+1)
-    if ((int64_t)p.imgs_per_wg * (H + 1) + 16 >= (1ll << 20)) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: stream too long");
+    // rows of the global stream per workgroup: all CUs busy whatever the batch, but no fewer than 24 rows each (two of a range's rows are
+    // recomputed for its neighbours)
+    const int64_t T = (int64_t)B * (H + 1);
+    if ((T + 16) * (int64_t)(H + 1) * (H + 1) >= (1ll << 32)) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: stream too long");
+    const int nwg_target = (int)std::max<int64_t>(1, std::min<int64_t>(ncu, (T + 23) / 24));
+    p.rows_per_wg = (int)((T + nwg_target - 1) / nwg_target);
+    static const bool whole_images = getenv("SR355_CHAIN_WHOLE_IMAGES") != nullptr;       // A/B switch (diagnostic): round 2's partition, ranges = whole images
+    if (whole_images) p.rows_per_wg = ((B + ncu - 1) / ncu) * (H + 1);
+    const int nwg = (int)((T + p.rows_per_wg - 1) / p.rows_per_wg);
+    p.magic = (unsigned)(((1ull << 32) + (unsigned)H) / (unsigned)(H + 1));                 // ceil(2^32 / (H+1)): exact quotient for g (H+1)^2 < 2^32 (checked above)
     p.alpha = alpha; p.xscale = tail ? beta_x / alpha : 0.f; p.oscale = tail && skip_o.p ? beta_o / alpha : 0.f;
     for (float sc : {p.xscale, p.oscale}) {   // the skips join the accumulators as scale * identity MFMA fragments in bf16: only exactly representable ratios (5 and 25 here)
         uint32_t u = (uint32_t)bf16_host(sc) << 16;
