@@ -28,12 +28,15 @@ def fused_ctx(ctx):
 
 
 CASES = [
-    # B, H, grid cap (0 = one workgroup per CU)
-    (3, 48, 0),      # the bench shape, one image per workgroup
-    (7, 48, 2),      # 4 + 3 images per workgroup: separator rows between images, uneven split
-    (5, 9, 2),       # height not a multiple of the 8-row step
-    (4, 1, 3),       # one-row images: every second stream row is a separator
-    (2, 17, 0),
+    # B, H, grid cap (0 = one workgroup per CU).  Round 3: a workgroup owns a range of the global row stream (B * (H + 1) rows, >= 24 per
+    # workgroup), so the ranges below cut images at many different offsets; the two rows a range recomputes for its neighbours are part of it
+    (3, 48, 0),      # the bench shape: 147 stream rows -> 7 ranges of 21 rows, every one starting or ending inside an image
+    (7, 48, 2),      # two ranges of 172 rows: separator rows inside a range, a cut in the middle of the fourth image
+    (5, 9, 2),       # height not a multiple of the 8-row step; two ranges of 25 rows
+    (4, 1, 3),       # one-row images: every second stream row is a separator (one range)
+    (2, 17, 0),      # two ranges that meet exactly at an image boundary
+    (3, 48, 5),      # five ranges of 30 rows
+    (6, 20, 4),      # four ranges of 32 rows over 21-row image periods
     (9, 8, 4),       # height == step
 ]
 
