@@ -202,8 +202,8 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qn2 = fmaxf(qn2, __shfl_xor(qn2, o));
-    const float qmax = __builtin_amdgcn_readfirstlane(sqrtf(qn2)) * 1.0009765625f;      // a 2^-10 margin over the fp32 rounding of norms and products
-    const float* knorm = p.knorm + (int64_t)b * ((N + KT2 - 1) / KT2);
+    const float qmaxv = sqrtf(qn2) * 1.0009765625f;      // wave-uniform (a 2^-10 margin over the fp32 rounding of norms and products)
+    const int* knorm_bits = reinterpret_cast<const int*>(p.knorm) + (int64_t)b * ((N + KT2 - 1) / KT2);
     f32x16 oacc[QB];
     // Row sums ride on the matrix core as well: a 16x16x32 MFMA with a 0/1 selector as A and the probability fragment (the PV
     // MFMA's B operand, reinterpreted) as B.  Lane (r, h) of the 32x32 layout is column r & 15, k-group 2h + (r >> 4) of the
@@ -233,9 +233,13 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
     bf16x8 kneg = {};
     kneg[0] = (bf16_t)-1.f; kneg[1] = (bf16_t)-1.f; kneg[2] = (bf16_t)-1.f;
     auto load_k = [&](int kb) {
+        // the lane number is re-derived here (two v_mbcnt) rather than kept: at the 168-register budget hipcc spilled the copy of r this address
+        // needs, and the reload's s_waitcnt vmcnt(0) at the head of every key group also waited for the key fragment requested just before
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         bf16x8 kf = kneg;
-        const int key = kb + r;
-        if (h == 0) kf = *reinterpret_cast<const bf16x8*>(base + (int64_t)(key < N ? key : N - 1) * cs + p.koff);
+        const int key = kb + (l & 31);
+        if (l < 32) kf = *reinterpret_cast<const bf16x8*>(base + (int64_t)(key < N ? key : N - 1) * cs + p.koff);
         return kf;
     };
     bf16x8 knext = load_k(0);
@@ -364,16 +368,23 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
         }
         return true;
     };
-    // smallest running max among the wave's queries (wave-uniform); refreshed after every group that ran the full logic
-    auto wave_min_m = [&]() {
+    // The group-level bound as ONE scalar integer compare per group.  |k|max |q|max - min m <= GROW_OK  <=>  |k|max <= (GROW_OK + min m) / |q|max =:
+    // thresh, and for non-negative floats the order of the values is the order of their bit patterns: thresh is kept as its bits in a scalar
+    // register (negative -- bound unreachable -- as -1.f, whose bits are a negative integer; +inf when every query is zero), refreshed only
+    // when the smallest running max among the wave's queries may have changed (after a group that ran the full logic).  gfx950 has no scalar
+    // float ALU: the first version evaluated the bound in vector registers per group, hipcc spilled |q|max at the 168-register budget, and the
+    // reload's s_waitcnt vmcnt(0) also waited for the key fragment just requested.
+    auto thresh_of_wave = [&]() -> int {
         float m = m_run[0];
 #pragma unroll
         for (int j = 1; j < QB; ++j) m = fminf(m, m_run[j]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
-        return __builtin_amdgcn_readfirstlane(m);
+        const float lim = GROW_OK + m;
+        const float th = !(lim >= 0.f) ? -1.f : (qmaxv > 0.f ? lim / qmaxv * 0.9990234375f : INFINITY);
+        return __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th));      // an integer builtin: the float travels as its bits
     };
-    float mmin = 0.f;
+    int thresh_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -1.f));      // until the first group has set the running maxima
     // V^T of KT2 keys into LDS, two keys per dword (every wave of the workgroup passes here once per key group, in either mode).
     // (Round 3 measured a double-buffered image with the rows requested a whole group ahead: no faster -- the loop is bound by vector
     // issue, 16 v_exp_f32 + 8 converts + 5 MFMAs per 32 x 32 scores, not by this staging -- and eight more live registers.)
@@ -415,7 +426,7 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
         const bool full = k0 != 0 && k0 + KT2 <= N;
         if (full) {
             // group-level bound (scalar): every score k.q - m of this group is <= |k|max |q|max - min m; where it holds the tiles run unguarded
-            const bool guard = !(knorm[k0 / KT2] * qmax - mmin <= GROW_OK);
+            const bool guard = !(knorm_bits[k0 / KT2] <= thresh_bits);       // NaN norms have bits above every finite threshold: guarded
 #pragma unroll
             for (; sub < KT2 / 32; ++sub) {
                 kf = knext;
@@ -427,7 +438,7 @@ __global__ void __launch_bounds__(256, 3) attn_bf16_kernel(AttnParams p) {
         }
         if (sub < KT2 / 32) {
             slow_tiles(k0, sub, kf);
-            mmin = wave_min_m();
+            thresh_bits = thresh_of_wave();
         }
     }
 #pragma unroll
