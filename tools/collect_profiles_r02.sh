@@ -17,12 +17,16 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 echo "WRITE_SIZE pass done"
 python3 tools/make_pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" $NDISP 7056 > "$OUT/pmc_traffic.log" 2>&1 && cp profiles/pmc_traffic.json "$OUT/pmc_traffic.json"
 python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/${TAG}_pmc_hbm_traffic_b7056.txt" 2>&1 || true
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --steps 2 --warmup 1 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err" || { echo "bench profile failed"; tail -5 "$OUT/bench.err"; exit 1; }
+# the profiled command carries only full-size launches of the hot kernels (no parity patches, no cfg3 / cfg4 rows), so that the per-kernel averages of
+# the stats file are directly the ones bench.py's HIP events report; the complete default line (parity, cpu_baseline, rows) is taken un-profiled below
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-rows --no-parity > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err" || { echo "bench profile failed"; tail -5 "$OUT/bench.err"; exit 1; }
 tail -1 "$OUT/${TAG}_bench.json" > "$OUT/${TAG}_bench.line" && mv "$OUT/${TAG}_bench.line" "$OUT/${TAG}_bench.json"
 cp "$(find "$OUT/bench" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
 echo "bench + kernel stats done"
+python3 bench.py > "$OUT/${TAG}_bench_default.tmp" 2> "$OUT/bench_default.err" && tail -1 "$OUT/${TAG}_bench_default.tmp" > "$OUT/${TAG}_bench_default.json"; rm -f "$OUT/${TAG}_bench_default.tmp"
+echo "default bench line done"
 for t in 2 4 8 16; do
-  python3 bench.py --tiles $t --tiles-per-call $t --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-profile 2>/dev/null | tail -1 >> "$OUT/${TAG}_tiles_sweep.jsonl" || echo "tiles $t failed"
+  python3 bench.py --tiles $t --tiles-per-call $t --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-profile --no-rows 2>/dev/null | tail -1 >> "$OUT/${TAG}_tiles_sweep.jsonl" || echo "tiles $t failed"
 done
 echo "tiles sweep done"
 rm -rf "$OUT/bench" ; find "$OUT/pmc_fetch" "$OUT/pmc_write" -name "*.csv" -size +8M -delete
