@@ -14,6 +14,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUS
     echo "## $k"
     python3 tools/pmc_kernel.py "$k" "$OUT/p1" "$OUT/p2"
   done
-} > "$OUT/r02_sq_fused_kernels.txt"
+} > "$OUT/r03_sq_fused_kernels.txt"
 find "$OUT" -name "*.csv" -size +4M -delete
-cat "$OUT/r02_sq_fused_kernels.txt"
+cat "$OUT/r03_sq_fused_kernels.txt"
