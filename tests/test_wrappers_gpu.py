@@ -339,3 +339,33 @@ def test_keras_h5_checkpoints_load_and_save(ctx, tmp_path):
     g2 = ESRGAN(compute_dtype="f32")
     g2.setup_model(scale_factor=2, from_trained=True, generator_pretrained_path=gp)
     assert g2.num_rrdb_blocks == 1 and all(np.array_equal(g2.weights[n][0], g.weights[n][0]) for n in g.weights)
+
+
+def test_cfg2_full_size_batch_properties(ctx):
+    """BASELINE configs[2] at its full size -- ESRGAN x4, NB = 23, G = 32, both SelfAttention layers, bf16, sixteen 512 x 512 LR tiles in
+    reference patch mode = 7056 patches 48 x 48 through one set of launches -- checked through properties that do not need the CPU oracle at
+    this size (the oracle pins the same graph on 36 patches in test_full_depth_generator_bf16_tracks_fp32 and stage by stage in
+    tests/test_full_depth_gpu.py): every tile's image from the 16-tile call is BIT FOR BIT the image of that tile processed on its own (441
+    patches: other launch shapes, other workgroup ranges of the fused kernels' row stream, other sub-batches everywhere), replicated tiles give
+    replicated images, shapes / range / finiteness, and the second call reproduces the first."""
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    from sr355.weights import condition_attention, init_weights
+    m = ESRGAN(compute_dtype="bf16")
+    m.setup_model(scale_factor=4, growth_channels=32, num_rrdb_blocks=23, use_attention=True)
+    m.set_weights(bf16_rounded(condition_attention(init_weights(m.generator.layer_shapes(), seed=3000))))
+    lr4, hr4 = make_pairs(4, 512, 512, 4, seed=44)
+    lr = ctx.to_device(np.stack([lr4[t % 4] for t in range(16)]))
+    srs, _ = m.super_resolve_images([lr[t] for t in range(16)], patch_size_lr=48, stride=24, batch_size=441 * 16, timed=False)
+    assert len(srs) == 16
+    for sr in srs:
+        assert tuple(sr.shape) == (2048, 2048, 3) and bool(torch.isfinite(sr).all()) and float(sr.min()) >= 0.0 and float(sr.max()) <= 1.0
+    for t in range(4, 16):
+        assert torch.equal(srs[t], srs[t % 4]), t                       # the batch holds each synthetic tile four times
+    for t in (0, 1, 2, 3):
+        alone = m.super_resolve_image(lr[t], patch_size_lr=48, stride=24, batch_size=441)[0]
+        assert torch.equal(alone, srs[t]), (t, float((alone - srs[t]).abs().max()))
+    again, _ = m.super_resolve_images([lr[t] for t in range(16)], patch_size_lr=48, stride=24, batch_size=441 * 16, timed=False)
+    assert all(torch.equal(a, b) for a, b in zip(again, srs))
+    p = [float(ctx.psnr(ctx.to_device(hr4[t:t + 1]), srs[t][None])[0]) for t in range(4)]
+    assert all(np.isfinite(p)), p
+    m.generator.release_workspace()
