@@ -118,12 +118,15 @@ struct Op {
     int act = SR_ACT_LINEAR; float alpha = 1.f, beta1 = 0.f, beta2 = 0.f; int clip = 0, d2s = 1;
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
     int chain = -1, chain_pos = 0;                  // conv: member (first / second) of m->chains[chain]
+    int rgbtail = -1;                               // conv: first op of m->rgbtails[rgbtail] (the next op is the conv folded into this one's epilogue)
 };
 struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs)
 struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
 struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; };
 // two consecutive convs of a dense block that run as ONE kernel when the shape allows (dense_fused.hip): ops[first], ops[first + 1]
 struct ChainSpec { int conv_a = -1, conv_b = -1; int tail = 0; ChainWeights w; };
+// a 64-cout 3x3 conv followed by the 3x3 conv to the image's <= 3 channels: one kernel + a finishing pass when the shape allows (conv_rows.hip)
+struct RgbTailSpec { int conv_b = -1; RgbTailWeights w; };
 
 }  // namespace
 
@@ -135,6 +138,7 @@ struct sr_model {
     std::vector<Param> params;
     std::vector<ConvSpec> convs;
     std::vector<ChainSpec> chains;
+    std::vector<RgbTailSpec> rgbtails;
     std::vector<BufSpec> bufs;
     std::vector<void*> bufp;
     std::vector<float*> dense_dev;    // per param index (dense kernels / biases on device), else nullptr
@@ -319,6 +323,13 @@ int build_esrgan(sr_model* m) {
     const int f1 = b.buf(64, mul);
     b.conv("final_conv1", 3, 64, 64, {cur, 0}, {f1, 0}, SR_ACT_RELU);
     b.conv("final_conv2", 3, 64, C, {f1, 0}, {-2, 0}, SR_ACT_TANH);
+    if (m->T == SR_DTYPE_BF16 && C <= 3) {
+        // final_conv2 can ride in final_conv1's epilogue (conv_rows.hip, rows_fuse2): the 64-channel image at the output resolution is
+        // then never written; sr_forward decides per call (a tap on final_conv1, or sr_debug_set_fused without bit 2, runs the two convs)
+        RgbTailSpec rt; rt.conv_b = m->ops.back().conv;
+        m->rgbtails.push_back(rt);
+        m->ops[m->ops.size() - 2].rgbtail = (int)m->rgbtails.size() - 1;
+    }
     return SR_OK;
 }
 
@@ -615,6 +626,7 @@ void sr_model_destroy(sr_model* m) {
     m->free_bufs();
     for (auto& c : m->convs) conv_free_weights(m->ctx, &c.w);
     for (auto& ch : m->chains) chain_free_weights(m->ctx, &ch.w);
+    for (auto& rt : m->rgbtails) rgbtail_free_weights(m->ctx, &rt.w);
     for (auto& p : m->dense_dev) if (p) m->ctx->dfree(p);
     delete m;
 }
@@ -735,6 +747,14 @@ int sr_model_finalize(sr_model* m) {
         int rc = chain_pack_weights(ctx, ka.data(), ba.data(), kb.data(), bb.data(), a.Cin / 32, a.Cout / 16, bq.Cout / 16, &ch.w);
         if (rc) return rc;
     }
+    for (auto& rt : m->rgbtails) {
+        rgbtail_free_weights(ctx, &rt.w);
+        const ConvSpec& c2 = m->convs[rt.conv_b];
+        std::vector<float> k, bias;
+        gather(c2, k, bias);
+        int rc = rgbtail_pack_weights(ctx, k.data(), bias.data(), c2.Cout, &rt.w);
+        if (rc) return rc;
+    }
     for (auto& op : m->ops) {
         if (op.kind != OP_DENSE) continue;
         for (int pi : {op.dw, op.db}) {
@@ -814,6 +834,23 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                         }
                         break;
                     }
+                }
+                if (op.rgbtail >= 0 && (ctx->chain_mask & 4) && m->taps.count((int)oi) == 0 && cs.w.rows && cs.w.NT == 4 && cs.w.Cout == 64 &&
+                    op.skip1.buf < 0 && op.skip2.buf < 0 && op.d2s == 1 && !op.clip && op.act != SR_ACT_TANH && op.out.buf >= 0 &&
+                    (int64_t)m->bufcap[op.out.buf] >= rgbtail_partial_bytes(B, h, w)) {
+                    // final_conv1 + final_conv2 as one kernel and a finishing pass; the partial sums live in the buffer final_conv1's
+                    // output would have taken (a tile's 3 KiB against the 24 KiB of its 64-channel pixels)
+                    const Op& ob = m->ops[oi + 1];
+                    const RgbTailSpec& rt = m->rgbtails[op.rgbtail];
+                    ConvEpilogue ep1;
+                    ep1.act = op.act; ep1.alpha = op.alpha;
+                    ep1.f2 = &rt.w; ep1.f2_part = static_cast<float*>(m->bufp[op.out.buf]);
+                    rc = conv_launch(ctx, cs.w, xin, B, h, w, TensorView{}, ep1, st);
+                    if (rc) return rc;
+                    rc = rgbtail_finish_launch(ctx, rt.w, ep1.f2_part, B, h, w, ob.act, ob.alpha, ob.clip, y, m->out_C, 0, io_dtype == SR_DTYPE_F32, st);
+                    if (rc) return rc;
+                    ++oi;                                             // the second conv has run
+                    break;
                 }
                 ConvEpilogue ep;
                 ep.act = op.act; ep.alpha = op.alpha; ep.clip01 = op.clip; ep.d2s_r = op.d2s;

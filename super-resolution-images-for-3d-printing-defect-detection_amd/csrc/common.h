@@ -55,7 +55,7 @@ struct sr_ctx {
     void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int cu_count();               // compute units of the device (queried once)
-    int chain_mask = 3;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3 (sr_debug_set_fused; default both)
+    int chain_mask = 7;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1 (sr_debug_set_fused; default all)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
 
@@ -113,7 +113,16 @@ struct TensorView {           // NHWC view with a channel stride/offset (element
     int blk = 0;              // 1: the buffer is row-blocked, [B][H][cs/32][W][32] (conv_common.h); cs, coff multiples of 32
 };
 
+// Fused RGB tail (conv_rows.hip, rows_fuse2): the 3x3 conv to c2 <= 3 channels that follows a 64-cout 3x3 conv, folded into that conv's epilogue
+struct RgbTailWeights {
+    void* a = nullptr;        // four 1 KiB MFMA A-fragments [tap-channel block][channel half], bf16
+    float* bias = nullptr;    // [3] fp32, zero padded
+    int c2 = 0;
+};
+
 struct ConvEpilogue {
+    const RgbTailWeights* f2 = nullptr;   // conv_rows, 64 couts, no skips: do not store this conv's output, write the following conv's partial sums to f2_part
+    float* f2_part = nullptr;             // rgbtail_partial_bytes(B, H, W) bytes
     int act = SR_ACT_LINEAR;
     float alpha = 1.f;
     TensorView skip1, skip2;  // same dtype as the conv's compute dtype; p == nullptr -> unused
@@ -135,6 +144,14 @@ void conv_free_weights(sr_ctx* ctx, ConvWeights* w);
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W,
                 void* y, int64_t y_cs, int y_coff, const ConvEpilogue& ep, hipStream_t st);
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W, TensorView y, const ConvEpilogue& ep, hipStream_t st);
+
+// fused RGB tail: pack the second conv's HWIO kernel [3,3,64,c2] (+ bias), size of the partial-sum buffer, and the pass that adds the
+// partial sums of the tiles covering an output pixel, applies bias / activation / alpha / clip and stores NHWC (bf16, or fp32 with out_f32)
+int rgbtail_pack_weights(sr_ctx* ctx, const float* w2_hwio, const float* bias2, int c2, RgbTailWeights* out);
+void rgbtail_free_weights(sr_ctx* ctx, RgbTailWeights* w);
+int64_t rgbtail_partial_bytes(int B, int H, int W);
+int rgbtail_finish_launch(sr_ctx* ctx, const RgbTailWeights& w, const float* part, int B, int H, int W, int act, float alpha, int clip01, void* y,
+                          int64_t y_cs, int y_coff, int out_f32, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // fused pair of dense-block convs (dense_fused.hip)

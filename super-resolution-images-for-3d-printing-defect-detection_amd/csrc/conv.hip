@@ -622,6 +622,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.alpha = ep.alpha; p.act = ep.act; p.clip = ep.clip01; p.r = r; p.Cd = w.Cout / (r * r);
     p.B = B; p.H = H; p.W = W; p.Cout = w.Cout; p.nchunks = w.nchunks; p.tilesX = p.tilesY = 0;
     p.dbg = ctx->stamp_buf;
+    p.f2w = nullptr; p.f2part = nullptr; p.f2c = 0;
     const int osz = p.out_f32 ? 4 : esz;
     bool vec = (y_cs % 4 == 0) && (y_coff % 4 == 0) && ((uintptr_t)y % (4 * osz) == 0) && (p.Cd % 4 == 0);
     if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);
@@ -636,9 +637,18 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         if (p.s2 && p.s2 == p.in && p.s2_cs == p.in_cs && p.s2_ps == p.in_ps && p.s2_coff == p.in_coff) { p.skip_lds = 2; p.skip_scale = p.beta2 / p.alpha; }
         else if (p.s1 && p.s1 == p.in && p.s1_cs == p.in_cs && p.s1_ps == p.in_ps && p.s1_coff == p.in_coff) { p.skip_lds = 1; p.skip_scale = p.beta1 / p.alpha; }
     }
+    if (ep.f2) {
+        if (!(w.rows && w.NT == 4 && w.Cout == 64 && w.CoutP == 64 && r == 1 && !p.s1 && !p.s2 && !ep.clip01 && ep.act != SR_ACT_TANH && ep.f2->a && ep.f2_part))
+            return ctx->fail(SR_ERR_INVALID, "conv: the fused RGB tail follows a bf16 3x3 conv to 64 channels without skips");
+        p.f2w = static_cast<const char*>(ep.f2->a); p.f2part = ep.f2_part; p.f2c = ep.f2->c2;
+    }
     const int nct = w.CoutP / 32 / w.NT;
     int rec = -1;
-    if (ctx->prof) {
+    if (ctx->prof && ep.f2) {
+        const double px = (double)B * H * W;
+        rec = ctx->prof_open("conv_rows_rgbtail<bf16,64->64->rgb>", 2.0 * px * 9 * w.Cin * (w.Cout + ep.f2->c2),
+                             px * w.Cin * esz + (double)rgbtail_partial_bytes(B, H, W), st);
+    } else if (ctx->prof) {
         char nm[96];
         snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.few ? "few" : w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),
                  w.dtype == SR_DTYPE_BF16 ? "bf16" : "f32", w.KS, w.KGPT, w.NT);

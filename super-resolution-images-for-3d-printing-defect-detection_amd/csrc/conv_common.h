@@ -23,6 +23,11 @@ struct ConvParams {
     int skip_lds;       // conv_rows: skip 1 / 2 (value 1 / 2) is input channels [0, Cout) of this conv -- folded in from LDS
     float skip_scale;   // its beta / alpha
     unsigned long long* dbg;   // diagnostic builds only: 16 s_memtime stamps per workgroup (sr_debug_set_stamp_buffer)
+    // conv_rows, fused RGB tail (conv_rows.hip, rows_fuse2): this conv's output is consumed on chip by the following 3x3 conv to f2c <= 3
+    // channels; the workgroup writes that conv's partial sums over its halo'd tile instead of its own 64-channel output
+    const char* f2w;    // the second conv's kernel as four 1 KiB MFMA A-fragments [t block][channel half] (rgbtail_pack_weights), or nullptr
+    float* f2part;      // [B][tilesY][tilesX][(TH + 2) * 18][3] fp32 partial sums
+    int f2c;            // the second conv's output channels
 };
 
 __device__ __forceinline__ int choff(int c, int ps) { return (c >> 5) * ps + (c & 31); }

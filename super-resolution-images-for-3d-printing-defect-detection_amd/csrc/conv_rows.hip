@@ -28,6 +28,10 @@
 // Prologue and epilogue are kept to a few hundred issue slots per wave (32-bit offsets from wave-uniform
 // 64-bit bases, branch-free activation, biases prefetched, skips loaded in bulk): in-kernel stamps showed
 // they, not the MFMAs, held the SIMDs in the first version.
+#include <string.h>
+
+#include <vector>
+
 #include "conv_rows_epi.h"
 
 namespace {
@@ -40,7 +44,81 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
 
 #define STAMP_AT(i) do { if (STAMP && tid == 0) p.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <int NB16, int R, bool STAMP>
+// Fused RGB tail (FUSE2; 64 couts per workgroup only).  The generator ends in final_conv1 (64 -> 64, ReLU) -> final_conv2 (64 -> 3, tanh)
+// (ESRGAN_model.py:339-341): layer by layer the 64-channel image at the output resolution is written and read back once -- 66 GB per
+// bench step, as much as final_conv1's own input -- for a conv that is 4 % of final_conv1's FLOP.  A 3x3 conv to C2 <= 3 channels is a 1x1
+// conv to 9 C2 <= 27 "tap channels" followed by a shifted sum,
+//     out[y][x][co] = sum_taps z[y + ky - 1][x + kx - 1][tap][co],   z[p][tap][co] = sum_c W2[tap][c][co] h[p][c],
+// and z of a pixel needs that pixel's h only -- which the epilogue holds in registers, already in the MFMA's B-operand shape: lane (px, q)
+// has channels 16 n + 4 q + e of pixel px for cout blocks n = 0..3, i.e. for a "channel half" (n = 2 half, 2 half + 1) eight bf16 values; the
+// K ordering of an MFMA is free as long as the A fragment (host-packed, rgbtail_pack_weights) uses the same one.  So: 4 MFMAs per output row
+// and wave give z (fp32, 32 tap channels); z goes to LDS; thread i < 14 * 18 sums, for position i of the tile's halo'd region, the taps whose
+// source pixel lies inside the tile, and stores 3 floats.  h is never written.  rgbtail_finish_kernel adds the <= 4 tiles' partial sums of
+// an output pixel in a fixed order, then bias, tanh, store.  h is rounded to bf16 before the 1x1 (what the layer-by-layer path stores), the
+// sums are fp32 throughout; only the order of the fp32 additions differs from the separate conv.
+template <int R>
+__device__ __forceinline__ void rows_fuse2(const ConvParams& p, f32x4 (&acc)[R][4], const f32x4 (&biasv)[4], char* smem, int64_t tile, int y0, int x0,
+                                           int wave, int lane, int px, int q, int tid) {
+    constexpr int TH = 4 * R, RW = 18, ZS = 36;             // ZS: floats per pixel in LDS (32 tap channels + 4: 16-lane ds_write_b128 groups hit 64 distinct banks)
+    const float slope = p.act == SR_ACT_RELU ? 0.f : (p.act == SR_ACT_LRELU ? 0.2f : 1.f);
+    const float alpha = p.alpha;
+    bf16x8 wa[2][2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) wa[tb][hf] = *reinterpret_cast<const bf16x8*>(p.f2w + ((tb * 2 + hf) * 64 + lane) * 16);
+    const int ox = x0 + px;
+    f32x4 z[R][2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool live = y0 + wave * R + r < p.H && ox < p.W;             // pixels of a ragged tile beyond the image contribute nothing
+        bf16x8 hb[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][2 * hf + u][e] + biasv[2 * hf + u][e];
+                    v = fmaxf(v, v * slope) * alpha;
+                    hb[hf][4 * u + e] = live ? (bf16_t)v : (bf16_t)0.f;
+                }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            z[r][tb] = mma16(wa[tb][0], hb[0], f32x4{0.f, 0.f, 0.f, 0.f});
+            z[r][tb] = mma16(wa[tb][1], hb[1], z[r][tb]);
+        }
+    }
+    __syncthreads();                                                       // every wave is done with the input image and the weights
+    float* zl = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) *reinterpret_cast<f32x4*>(zl + ((wave * R + r) * 16 + px) * ZS + 16 * tb + 4 * q) = z[r][tb];
+    __syncthreads();
+    if (tid < (TH + 2) * RW) {
+        const int ry = tid / RW, rx = tid - ry * RW, c2 = p.f2c;
+        float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = ry + ky - 2;                                    // source pixel (tile-local) of tap (ky, kx) for output (y0 - 1 + ry, x0 - 1 + rx)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = rx + kx - 2;
+                if ((unsigned)sy < (unsigned)TH && (unsigned)sx < 16u) {
+                    const float* zp = zl + (sy * 16 + sx) * ZS + (ky * 3 + kx) * c2;
+#pragma unroll
+                    for (int co = 0; co < 3; ++co)
+                        if (co < c2) s[co] += zp[co];
+                }
+            }
+        }
+        float* dst = p.f2part + (tile * ((TH + 2) * RW) + tid) * 3;
+        dst[0] = s[0]; dst[1] = s[1]; dst[2] = s[2];
+    }
+}
+
+template <int NB16, int R, bool STAMP, bool FUSE2 = false>
 __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(ConvParams p) {
     constexpr int TH = 4 * R, TW = 16, PH = TH + 2, PW = TW + 2;
     constexpr int NPIX = PH * PW;
@@ -254,6 +332,12 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
     f32x4 biasv[NB16];
 #pragma unroll
     for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
+    if constexpr (FUSE2) {
+        static_assert(!FUSE2 || NB16 == 4, "the fused RGB tail needs all 64 channels of a pixel in one workgroup");
+        rows_fuse2<R>(p, acc, biasv, smem, ((int64_t)b * p.tilesY + ty) * tilesX + tx, y0, x0, wave, lane, px, q, tid);
+        STAMP_AT(15);
+        return;
+    }
     if constexpr (SKIP_LDS_OK) if (skip_lds) {
         ConvParams pe = p;                                                  // the epilogue sees only the other skip, as skip 1
         if (p.skip_lds == 1) { pe.s1 = p.s2; pe.s1_cs = p.s2_cs; pe.s1_coff = p.s2_coff; pe.s1_ps = p.s2_ps; pe.s1_rs = p.s2_rs; pe.beta1 = p.beta2; }
@@ -272,6 +356,7 @@ template <int NB16>
 int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     constexpr int R = NB16 == 4 ? 3 : 4;
     constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024 + NB16 * 64;
+    static_assert(NB16 != 4 || (4 * R * 16 * 36 * 4 <= lds && R == 3), "rows_fuse2 parks its tap channels in the tile's LDS; the finishing pass assumes 12 x 16 tiles");
     ConvParams p = p0;
     const int tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 4 * R - 1) / (4 * R);
@@ -280,7 +365,7 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     if (nwg >= (1ll << 31)) return ctx->fail(SR_ERR_INVALID, "conv_rows: too many workgroups for one launch");
     p.tilesX = (nct << 16) | tilesX;
     dim3 grid((unsigned)nwg, 1u);
-    if (p.dbg) {   // diagnostic stamped variant: 16 stamps per workgroup, refused when the buffer is too small for this grid
+    if (p.dbg && !p.f2w) {   // diagnostic stamped variant: 16 stamps per workgroup, refused when the buffer is too small for this grid
         if (nwg * 16 * (int64_t)sizeof(unsigned long long) > ctx->stamp_cap)
             return ctx->fail(SR_ERR_INVALID, "conv_rows: the stamp buffer is too small for this launch (sr_debug_stamp_bytes_needed(0, workgroups))");
         auto kd = conv3_rows_kernel<NB16, R, true>;
@@ -289,6 +374,17 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
         SR_HIP(ctx, hipGetLastError());
         return SR_OK;
     }
+    if constexpr (NB16 == 4) {
+        if (p.f2w) {
+            if (nct != 1) return ctx->fail(SR_ERR_INVALID, "conv_rows: the fused RGB tail needs a 64-cout conv");
+            auto kf = conv3_rows_kernel<NB16, R, false, true>;
+            if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kf), lds)) return rc;
+            hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, p);
+            SR_HIP(ctx, hipGetLastError());
+            return SR_OK;
+        }
+    }
+    if (p.f2w) return ctx->fail(SR_ERR_INVALID, "conv_rows: the fused RGB tail needs a 64-cout conv");
     auto kern = conv3_rows_kernel<NB16, R, false>;
     if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
@@ -297,6 +393,108 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
 }
 
 }  // namespace
+
+// ---- fused RGB tail: host side and the finishing pass ------------------------------------------------------------------------------
+namespace {
+
+constexpr int F2_TH = 12, F2_TW = 16, F2_REGION = (F2_TH + 2) * (F2_TW + 2);    // tile of the 64-cout variant (R = 3) and its halo'd region
+
+uint16_t bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// one thread per output pixel: its own tile's partial sum, then the neighbours whose halo'd region covers it (a pixel in a tile's first /
+// last row or column is also a halo position of the tile above / below / beside, and of the diagonal one in a corner), always in this order
+__global__ void __launch_bounds__(256) rgbtail_finish_kernel(const float* __restrict__ part, int64_t npix, int H, int W, int tilesY, int tilesX,
+                                                             const float* __restrict__ bias, int c2, int act, float alpha, int clip, char* out,
+                                                             int64_t out_cs, int out_coff, int out_f32) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int x = (int)(i % W);
+    const int64_t row = i / W;
+    const int y = (int)(row % H);
+    const int64_t b = row / H;
+    const int ty = y / F2_TH, ry = y - ty * F2_TH + 1, tx = x / F2_TW, rx = x - tx * F2_TW + 1;
+    float s[3] = {0.f, 0.f, 0.f};
+    auto add = [&](int ty_, int tx_, int ry_, int rx_) {
+        const float* q = part + (((b * tilesY + ty_) * tilesX + tx_) * F2_REGION + ry_ * (F2_TW + 2) + rx_) * 3;
+        s[0] += q[0]; s[1] += q[1]; s[2] += q[2];
+    };
+    add(ty, tx, ry, rx);
+    const int vy = ry == 1 && ty > 0 ? -1 : (ry == F2_TH && ty + 1 < tilesY ? 1 : 0);
+    const int vx = rx == 1 && tx > 0 ? -1 : (rx == F2_TW && tx + 1 < tilesX ? 1 : 0);
+    const int nry = vy < 0 ? F2_TH + 1 : 0, nrx = vx < 0 ? F2_TW + 1 : 0;
+    if (vy) add(ty + vy, tx, nry, rx);
+    if (vx) add(ty, tx + vx, ry, nrx);
+    if (vy && vx) add(ty + vy, tx + vx, nry, nrx);
+    for (int co = 0; co < c2; ++co) {
+        float v = convk::act_apply(s[co] + bias[co], act) * alpha;
+        if (clip) v = fminf(fmaxf(v, 0.f), 1.f);
+        const int64_t e = i * out_cs + out_coff + co;
+        if (out_f32) reinterpret_cast<float*>(out)[e] = v;
+        else reinterpret_cast<bf16_t*>(out)[e] = (bf16_t)v;
+    }
+}
+
+}  // namespace
+
+// A fragment [tb][half]: lane l (tap channel i = l & 15 of block tb, k-quarter q = l >> 4), element j: W2'[t = 16 tb + i][channel 16 (2 half + (j >> 2)) + 4 q + (j & 3)]
+// with t = (ky * 3 + kx) * c2 + co -- the channel order rows_fuse2's B fragments have (the accumulator layout of the 64-cout epilogue)
+int rgbtail_pack_weights(sr_ctx* ctx, const float* w2, const float* bias2, int c2, RgbTailWeights* out) {
+    if (c2 < 1 || c2 > 3) return ctx->fail(SR_ERR_INVALID, "fused RGB tail: 1..3 output channels");
+    std::vector<uint16_t> host(4 * 512, 0);
+    for (int tb = 0; tb < 2; ++tb)
+        for (int hf = 0; hf < 2; ++hf)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 16 * tb + (l & 15);
+                    if (t >= 9 * c2) continue;
+                    const int tap = t / c2, co = t - tap * c2;
+                    const int c = 16 * (2 * hf + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+                    host[((tb * 2 + hf) * 64 + l) * 8 + j] = bf16_bits(w2[((size_t)tap * 64 + c) * c2 + co]);
+                }
+    RgbTailWeights w;
+    w.c2 = c2;
+    w.a = ctx->dalloc(host.size() * 2);
+    if (!w.a) return SR_ERR_OOM;
+    w.bias = static_cast<float*>(ctx->dalloc(3 * sizeof(float)));
+    if (!w.bias) { ctx->dfree(w.a); return SR_ERR_OOM; }
+    float hb[3] = {0.f, 0.f, 0.f};
+    if (bias2) for (int i = 0; i < c2; ++i) hb[i] = bias2[i];
+    SR_HIP(ctx, hipMemcpy(w.a, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    SR_HIP(ctx, hipMemcpy(w.bias, hb, sizeof hb, hipMemcpyHostToDevice));
+    *out = w;
+    return SR_OK;
+}
+
+void rgbtail_free_weights(sr_ctx* ctx, RgbTailWeights* w) {
+    if (w->a) ctx->dfree(w->a);
+    if (w->bias) ctx->dfree(w->bias);
+    w->a = nullptr; w->bias = nullptr;
+}
+
+int64_t rgbtail_partial_bytes(int B, int H, int W) {
+    return (int64_t)B * ((H + F2_TH - 1) / F2_TH) * ((W + F2_TW - 1) / F2_TW) * F2_REGION * 3 * (int64_t)sizeof(float);
+}
+
+int rgbtail_finish_launch(sr_ctx* ctx, const RgbTailWeights& w, const float* part, int B, int H, int W, int act, float alpha, int clip01, void* y,
+                          int64_t y_cs, int y_coff, int out_f32, hipStream_t st) {
+    const int64_t npix = (int64_t)B * H * W;
+    if (npix <= 0 || !part || !y || !w.a) return ctx->fail(SR_ERR_INVALID, "fused RGB tail: bad arguments");
+    const int64_t nwg = (npix + 255) / 256;
+    if (nwg >= (1ll << 31)) return ctx->fail(SR_ERR_INVALID, "fused RGB tail: too many pixels for one launch");
+    int rec = -1;
+    if (ctx->prof) rec = ctx->prof_open("rgbtail_finish", 0.0, (double)rgbtail_partial_bytes(B, H, W) + (double)npix * w.c2 * (out_f32 ? 4 : 2), st);
+    hipLaunchKernelGGL(rgbtail_finish_kernel, dim3((unsigned)nwg), dim3(256), 0, st, part, npix, H, W, (H + F2_TH - 1) / F2_TH, (W + F2_TW - 1) / F2_TW,
+                       w.bias, w.c2, act, alpha, clip01, static_cast<char*>(y), y_cs, y_coff, out_f32);
+    ctx->prof_close(rec, st);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
 
 int conv_rows_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams& p, hipStream_t st) {
     const int nct = w.CoutP / 16 / w.NT;   // NT holds NB16 for this variant

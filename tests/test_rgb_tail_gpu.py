@@ -1,0 +1,129 @@
+"""The generator's last two convs as one kernel (csrc/conv_rows.hip, rows_fuse2 + rgbtail_finish_kernel): final_conv2 (64 -> image
+channels, tanh; ESRGAN_model.py:341) is computed inside final_conv1's epilogue as a 1x1 conv to 9 x C "tap channels" followed by a shifted
+sum over each tile's halo'd region, so final_conv1's 64-channel output is never stored.  Checked against the two-kernel path
+(sr_debug_set_fused without bit 2) and against the CPU oracle: tile-exact, ragged and multi-tile images, one and three image channels,
+fp32 and bf16 caller tensors, and an exact-integer case in which both device paths and the oracle must agree to the last bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as M
+from sr355 import Model
+from sr355.weights import bf16_rounded, init_weights, round_to_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fused_ctx(ctx):
+    yield ctx
+    ctx.set_fused(7, 0)
+
+
+def kernels_of(ctx, fn):
+    ctx.profile_begin()
+    y = fn()
+    torch.cuda.synchronize()
+    return y, {r["kernel"] for r in ctx.profile_end()}
+
+
+# (B, LR height, LR width, scale, channels): the output tile of the 64-cout kernel is 12 x 16
+CASES = [
+    (1, 6, 8, 2, 3),        # 12 x 16: exactly one tile -- only the tile's own sums
+    (2, 7, 9, 2, 3),        # 14 x 18: 2 x 2 tiles, the second row / column of tiles two pixels deep (ragged: masked source pixels)
+    (3, 12, 16, 2, 3),      # 24 x 32: 2 x 2 full tiles, every interior border crossed by the 3x3 window
+    (2, 24, 24, 4, 3),      # 96 x 96: 8 x 6 tiles, two up-sampling stages (the bench's layer shapes at half size)
+    (1, 5, 13, 2, 1),       # one image channel: 9 tap channels
+    (2, 3, 3, 4, 3),        # 12 x 12: one ragged tile column
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("io", ["f32", "bf16"])
+def test_rgb_tail_matches_two_kernel_path_and_oracle(fused_ctx, case, io):
+    ctx = fused_ctx
+    B, H, W, s, C = case
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=s, channels=C, num_blocks=1, growth_channels=32, use_attention=False, ctx=ctx)
+    w = bf16_rounded(init_weights(m.layer_shapes(), seed=5100 + H))
+    m.set_weights(w)
+    x = round_to_bf16(np.random.default_rng(17 * H + W).uniform(-1, 1, (B, H, W, C)).astype(np.float32))
+    xd = ctx.to_device(x, torch.float32 if io == "f32" else torch.bfloat16)
+    ctx.set_fused(3, 0)
+    y0, k0 = kernels_of(ctx, lambda: m.forward(xd))
+    ctx.set_fused(7, 0)
+    y1, k1 = kernels_of(ctx, lambda: m.forward(xd))
+    assert not any("rgbtail" in k for k in k0)
+    assert any(k.startswith("conv_rows_rgbtail") for k in k1) and "rgbtail_finish" in k1, k1      # the fused path is the one that ran
+    assert torch.equal(y1, m.forward(xd))                                                         # deterministic: fixed order of the partial sums
+    a, b = y0.float().cpu().numpy(), y1.float().cpu().numpy()
+    assert a.shape == (B, H * s, W * s, C)
+    # same products, same bf16 roundings of final_conv1's output; only the order of the fp32 additions differs (tanh output in [-1, 1])
+    tol = 2e-6 if io == "f32" else 2.0 ** -8
+    assert np.abs(a - b).max() <= tol, float(np.abs(a - b).max())
+    ref = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=io == "bf16")
+    e0, e1 = np.abs(a - ref).max(), np.abs(b - ref).max()
+    assert e1 <= max(2.0 * e0, 1e-5) + (2.0 ** -8 if io == "bf16" else 0.0), (float(e0), float(e1))
+    # a tap on final_conv1 needs that conv's output in memory: the pair then runs as two kernels and the tap holds the activation
+    parts = {}
+    M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, parts=parts)
+    y2, taps = m.forward_with_taps(xd, ["final_conv1"])
+    assert torch.equal(y2, y0)
+    t = taps["final_conv1"].cpu().numpy()
+    assert np.abs(t - parts["final_conv1"]).max() <= 2.0 ** -7 * max(1.0, np.abs(parts["final_conv1"]).max())
+
+
+def test_rgb_tail_exact_integers(fused_ctx):
+    """Index arithmetic, exactly: with small non-negative integers everywhere (so LeakyReLU is the identity and every bf16 rounding is
+    exact) the pre-activation of final_conv2 is an exactly representable integer whatever the order of the additions, so the fused
+    kernel, the two-kernel path and the oracle must produce the SAME tanh values -- over ragged tiles, image borders and a batch."""
+    ctx = fused_ctx
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, channels=3, num_blocks=0, growth_channels=32, use_attention=False, ctx=ctx)
+    rng = np.random.default_rng(11)
+    w = {}
+    for name, shape in m.layer_shapes():
+        k = np.zeros(shape, np.float32)
+        b = np.zeros(shape[-1], np.float32)
+        if name == "initial_conv":
+            k[1, 1] = rng.integers(0, 2, size=shape[2:])
+        elif name in ("trunk_conv", "upsample_0_conv"):
+            nz = rng.random(shape) < 0.004
+            k[nz] = 1.0
+        elif name == "final_conv1":
+            nz = rng.random(shape) < 0.01
+            k[nz] = rng.integers(-1, 2, size=int(nz.sum()))
+            b = rng.integers(0, 2, size=shape[-1]).astype(np.float32)
+        elif name == "final_conv2":
+            nz = rng.random(shape) < 0.05
+            k[nz] = rng.integers(-1, 2, size=int(nz.sum())) * 2.0 ** -7        # a power of two: still exact, and tanh stays unsaturated (|pre-activation| < 1.4)
+        w[name] = (k, b)
+    m.set_weights(w)
+    x = rng.integers(0, 3, size=(3, 13, 21, 3)).astype(np.float32)               # 26 x 42 output: 3 x 3 tiles, ragged both ways
+    xd = ctx.to_device(x, torch.float32)
+    parts = {}
+    ref = M.esrgan_g_forward(x, w, 2, 0, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=False, parts=parts)
+    h = parts["final_conv1"]
+    assert np.array_equal(h, np.round(h)) and 0 < h.max() < 256, float(h.max())   # the premise: exact in bf16, and not all zeros
+    ctx.set_fused(3, 0)
+    y0 = m.forward(xd).cpu().numpy()
+    ctx.set_fused(7, 0)
+    y1, k1 = kernels_of(ctx, lambda: m.forward(xd))
+    assert any(k.startswith("conv_rows_rgbtail") for k in k1)
+    y1 = y1.cpu().numpy()
+    assert len(np.unique(y1)) > 100                                                 # a non-trivial image
+    assert np.array_equal(y0, y1), (float(np.abs(y0 - y1).max()), np.argwhere(y0 != y1)[:5])
+    assert np.abs(y1 - ref).max() <= 1e-6, float(np.abs(y1 - ref).max())         # tanhf against the fp64 tanh of the same integer
+
+
+def test_rgb_tail_falls_back_when_the_workspace_is_too_small(fused_ctx):
+    """The partial sums live in the buffer final_conv1's output would have taken; an image so small that one tile's 3 KiB of sums exceed
+    its 64-channel pixels (plus the workspaces' 4 KiB of slack) runs as two kernels: two 2 x 2 images = 6048 bytes of sums against 5120."""
+    ctx = fused_ctx
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, channels=3, num_blocks=1, growth_channels=32, use_attention=False, ctx=ctx)
+    w = bf16_rounded(init_weights(m.layer_shapes(), seed=9))
+    m.set_weights(w)
+    x = round_to_bf16(np.random.default_rng(2).uniform(-1, 1, (2, 1, 1, 3)).astype(np.float32))
+    xd = ctx.to_device(x, torch.float32)
+    y, ks = kernels_of(ctx, lambda: m.forward(xd))
+    assert not any("rgbtail" in k for k in ks)
+    ref = M.esrgan_g_forward(x, w, 2, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=False)
+    assert np.abs(y.cpu().numpy() - ref).max() <= 2e-2
