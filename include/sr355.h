@@ -99,7 +99,8 @@ int  sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer, int64
 int64_t sr_debug_stamp_bytes_needed(int which, int64_t workgroups);
 /* Which dense-block conv pairs of the ESRGAN trunk run as one fused line-buffer kernel when the shape allows (bf16, 32 growth
  * channels, 48-pixel-wide images): bit 0 = conv4+conv5, bit 1 = conv2+conv3; bit 2 = the generator's last conv (64 -> image channels,
- * ESRGAN_model.py:341) computed inside final_conv1's epilogue, so that final_conv1's 64-channel output is never stored; default 7.
+ * ESRGAN_model.py:341) computed inside final_conv1's epilogue, so that final_conv1's 64-channel output is never stored; bit 3 = the three
+ * 1x1 projections that open a SelfAttention layer (ESRGAN_model.py:48-56) computed in the epilogue of the conv producing its input; default 15.
  * mask 0 = layer by layer (the A/B switch of the parity tests and of tools/ benchmarks).  max_workgroups > 0 caps the persistent grid (tests: several images per workgroup
  * at small batches); 0 = one workgroup per CU. */
 int  sr_debug_set_fused(sr_ctx* ctx, int mask, int max_workgroups);

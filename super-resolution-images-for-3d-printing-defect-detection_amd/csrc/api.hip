@@ -119,6 +119,7 @@ struct Op {
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
     int chain = -1, chain_pos = 0;                  // conv: member (first / second) of m->chains[chain]
     int rgbtail = -1;                               // conv: first op of m->rgbtails[rgbtail] (the next op is the conv folded into this one's epilogue)
+    int proj = -1;                                  // conv: the next op is the 1x1 projection m->projs[proj], which this conv's epilogue can compute
 };
 struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs)
 struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
@@ -127,6 +128,8 @@ struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; Co
 struct ChainSpec { int conv_a = -1, conv_b = -1; int tail = 0; ChainWeights w; };
 // a 64-cout 3x3 conv followed by the 3x3 conv to the image's <= 3 channels: one kernel + a finishing pass when the shape allows (conv_rows.hip)
 struct RgbTailSpec { int conv_b = -1; RgbTailWeights w; };
+// the f / g / h projections of a SelfAttention layer, computed in the epilogue of the conv that produces the layer's input (conv_rows.hip)
+struct ProjSpec { int conv = -1; ProjWeights w; };
 
 }  // namespace
 
@@ -139,6 +142,7 @@ struct sr_model {
     std::vector<ConvSpec> convs;
     std::vector<ChainSpec> chains;
     std::vector<RgbTailSpec> rgbtails;
+    std::vector<ProjSpec> projs;
     std::vector<BufSpec> bufs;
     std::vector<void*> bufp;
     std::vector<float*> dense_dev;    // per param index (dense kernels / biases on device), else nullptr
@@ -192,7 +196,14 @@ struct Builder {
         // matrix core subtract the running max (attention.hip), so nothing is left to scale per score
         const float kscale = m->T == SR_DTYPE_BF16 ? 1.4426950408889634f : 1.f;
         Op p; p.kind = OP_CONV; p.conv = conv_spec({{name + "_f", 8, kscale}, {name + "_g", 8}, {name + "_h", 32}}, 1, 64);
-        p.in = {x, 0}; p.out = {qkv, 0}; m->ops.push_back(p);
+        p.in = {x, 0}; p.out = {qkv, 0};
+        if (m->T == SR_DTYPE_BF16 && !m->ops.empty() && m->ops.back().kind == OP_CONV && m->ops.back().out.buf == x && m->ops.back().out.coff == 0) {
+            // the conv that has just produced x can compute these 48 channels in its epilogue (conv_rows.hip, rows_epilogue_proj); sr_forward decides per call
+            ProjSpec ps; ps.conv = p.conv;
+            m->projs.push_back(ps);
+            m->ops.back().proj = (int)m->projs.size() - 1;
+        }
+        m->ops.push_back(p);
         Op a; a.kind = OP_ATTN; a.in = {qkv, 0}; a.out = {ao, 0}; m->ops.push_back(a);
         Op& v = conv(name + "_v", 1, 32, 64, {ao, 0}, {y, 0});
         v.skip1 = {x, 0}; v.beta1 = 1.f;
@@ -627,6 +638,7 @@ void sr_model_destroy(sr_model* m) {
     for (auto& c : m->convs) conv_free_weights(m->ctx, &c.w);
     for (auto& ch : m->chains) chain_free_weights(m->ctx, &ch.w);
     for (auto& rt : m->rgbtails) rgbtail_free_weights(m->ctx, &rt.w);
+    for (auto& pj : m->projs) proj_free_weights(m->ctx, &pj.w);
     for (auto& p : m->dense_dev) if (p) m->ctx->dfree(p);
     delete m;
 }
@@ -755,6 +767,14 @@ int sr_model_finalize(sr_model* m) {
         int rc = rgbtail_pack_weights(ctx, k.data(), bias.data(), c2.Cout, &rt.w);
         if (rc) return rc;
     }
+    for (auto& pj : m->projs) {
+        proj_free_weights(ctx, &pj.w);
+        const ConvSpec& c1 = m->convs[pj.conv];
+        std::vector<float> k, bias;
+        gather(c1, k, bias);
+        int rc = proj_pack_weights(ctx, k.data(), bias.data(), c1.Cout, &pj.w);
+        if (rc) return rc;
+    }
     for (auto& op : m->ops) {
         if (op.kind != OP_DENSE) continue;
         for (int pi : {op.dw, op.db}) {
@@ -798,6 +818,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
     if (rc) return rc;
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     const int T = m->T;
+    int proj_done = -1;                                                       // index of a 1x1 projection op the previous conv's epilogue has already computed
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const Op& op = m->ops[oi];
         int h = H, w = W;
@@ -808,6 +829,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 break;
             case OP_CONV: {
                 const ConvSpec& cs = m->convs[op.conv];
+                if ((int)oi == proj_done) break;                              // computed by the producing conv (its output buffer holds the result; a tap reads it below)
                 TensorView xin{m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, m->bufs[op.in.buf].blk};
                 if (op.chain >= 0) {
                     const ChainSpec& ch = m->chains[op.chain];
@@ -856,6 +878,14 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 ep.act = op.act; ep.alpha = op.alpha; ep.clip01 = op.clip; ep.d2s_r = op.d2s;
                 if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff, m->bufs[op.skip1.buf].blk}; ep.beta1 = op.beta1; }
                 if (op.skip2.buf >= 0) { ep.skip2 = {m->bufp[op.skip2.buf], m->bufs[op.skip2.buf].Cbuf, op.skip2.coff, m->bufs[op.skip2.buf].blk}; ep.beta2 = op.beta2; }
+                if (op.proj >= 0 && (ctx->chain_mask & 8) && cs.w.rows && cs.w.NT == 4 && cs.w.Cout / (op.d2s * op.d2s) == 64 && cs.w.CoutP == cs.w.Cout &&
+                    op.out.buf >= 0 && !m->bufs[op.out.buf].blk && op.skip2.buf < 0 && !op.clip && op.act != SR_ACT_TANH && m->bufs[op.out.buf].Cbuf % 4 == 0) {
+                    // the SelfAttention layer that follows opens with three 1x1 convs of this conv's output: computed here, from registers
+                    const Op& oq = m->ops[oi + 1];
+                    ep.pj = &m->projs[op.proj].w;
+                    ep.pj_out = TensorView{m->bufp[oq.out.buf], m->bufs[oq.out.buf].Cbuf, oq.out.coff, m->bufs[oq.out.buf].blk};
+                    proj_done = (int)oi + 1;
+                }
                 if (op.out.buf == -2) {
                     ep.out_f32 = io_dtype == SR_DTYPE_F32;
                     rc = conv_launch(ctx, cs.w, xin, B, h, w, y, m->out_C, 0, ep, st);

@@ -55,7 +55,7 @@ struct sr_ctx {
     void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int cu_count();               // compute units of the device (queried once)
-    int chain_mask = 7;           // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1 (sr_debug_set_fused; default all)
+    int chain_mask = 15;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue (sr_debug_set_fused; default all)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
 
@@ -120,7 +120,16 @@ struct RgbTailWeights {
     int c2 = 0;
 };
 
+// Fused 1x1 projection (conv_rows.hip, rows_epilogue_proj): a 1x1 conv of a 64-channel conv output to 16 * nblk <= 48 channels
+struct ProjWeights {
+    void* a = nullptr;        // [nblk][2] 1 KiB MFMA A-fragments, bf16
+    float* bias = nullptr;    // [16 * nblk] fp32
+    int nblk = 0;
+};
+
 struct ConvEpilogue {
+    const ProjWeights* pj = nullptr;      // conv_rows, 64 couts per output pixel, NHWC output: also write the 1x1 projection of the output to pj_out
+    TensorView pj_out;                    // NHWC bf16 view at the conv's output resolution, >= 16 * nblk channels from coff
     const RgbTailWeights* f2 = nullptr;   // conv_rows, 64 couts, no skips: do not store this conv's output, write the following conv's partial sums to f2_part
     float* f2_part = nullptr;             // rgbtail_partial_bytes(B, H, W) bytes
     int act = SR_ACT_LINEAR;
@@ -145,6 +154,9 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
                 void* y, int64_t y_cs, int y_coff, const ConvEpilogue& ep, hipStream_t st);
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W, TensorView y, const ConvEpilogue& ep, hipStream_t st);
 
+// fused 1x1 projection: pack the HWIO kernel [1,1,64,16 * nblk] (+ bias) of the 1x1 conv that follows a 64-channel conv_rows conv
+int proj_pack_weights(sr_ctx* ctx, const float* w_hwio, const float* bias, int cout, ProjWeights* out);
+void proj_free_weights(sr_ctx* ctx, ProjWeights* w);
 // fused RGB tail: pack the second conv's HWIO kernel [3,3,64,c2] (+ bias), size of the partial-sum buffer, and the pass that adds the
 // partial sums of the tiles covering an output pixel, applies bias / activation / alpha / clip and stores NHWC (bf16, or fp32 with out_f32)
 int rgbtail_pack_weights(sr_ctx* ctx, const float* w2_hwio, const float* bias2, int c2, RgbTailWeights* out);

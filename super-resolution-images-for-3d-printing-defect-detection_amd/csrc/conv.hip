@@ -623,6 +623,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.B = B; p.H = H; p.W = W; p.Cout = w.Cout; p.nchunks = w.nchunks; p.tilesX = p.tilesY = 0;
     p.dbg = ctx->stamp_buf;
     p.f2w = nullptr; p.f2part = nullptr; p.f2c = 0;
+    p.pjw = nullptr; p.pjbias = nullptr; p.pjout = nullptr; p.pj_cs = 0; p.pj_coff = 0; p.pj_rs = 0; p.pj_nblk = 0;
     const int osz = p.out_f32 ? 4 : esz;
     bool vec = (y_cs % 4 == 0) && (y_coff % 4 == 0) && ((uintptr_t)y % (4 * osz) == 0) && (p.Cd % 4 == 0);
     if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);
@@ -637,6 +638,16 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         if (p.s2 && p.s2 == p.in && p.s2_cs == p.in_cs && p.s2_ps == p.in_ps && p.s2_coff == p.in_coff) { p.skip_lds = 2; p.skip_scale = p.beta2 / p.alpha; }
         else if (p.s1 && p.s1 == p.in && p.s1_cs == p.in_cs && p.s1_ps == p.in_ps && p.s1_coff == p.in_coff) { p.skip_lds = 1; p.skip_scale = p.beta1 / p.alpha; }
     }
+    if (ep.pj) {
+        // every output pixel's 64 channels come from one workgroup: a 64-cout conv, or depth_to_space of 64-channel sub-pixels
+        if (!(w.rows && w.NT == 4 && p.Cd == 64 && w.CoutP == w.Cout && !yv.blk && !p.s2 && !ep.clip01 && ep.act != SR_ACT_TANH && vec && !ep.f2 && ep.pj->a &&
+              ep.pj->nblk >= 1 && ep.pj->nblk <= 3 && ep.pj_out.p && !ep.pj_out.blk && ep.pj_out.cs - ep.pj_out.coff >= 16 * ep.pj->nblk && ep.pj_out.cs % 4 == 0 &&
+              ep.pj_out.coff % 4 == 0 && (int64_t)H * r * W * r * ep.pj_out.cs < ((int64_t)1 << 31)))
+            return ctx->fail(SR_ERR_INVALID, "conv: the fused 1x1 projection follows a bf16 3x3 conv whose output pixels have 64 channels (NHWC, at most one skip)");
+        p.pjw = static_cast<const char*>(ep.pj->a); p.pjbias = ep.pj->bias; p.pj_nblk = ep.pj->nblk;
+        p.skip_lds = 0; p.skip_scale = 0.f;                       // the projection epilogue adds skip 1 itself
+        p.pjout = static_cast<char*>(const_cast<void*>(ep.pj_out.p)); p.pj_cs = ep.pj_out.cs; p.pj_coff = ep.pj_out.coff; p.pj_rs = (int)(W * r * ep.pj_out.cs);
+    }
     if (ep.f2) {
         if (!(w.rows && w.NT == 4 && w.Cout == 64 && w.CoutP == 64 && r == 1 && !p.s1 && !p.s2 && !ep.clip01 && ep.act != SR_ACT_TANH && ep.f2->a && ep.f2_part))
             return ctx->fail(SR_ERR_INVALID, "conv: the fused RGB tail follows a bf16 3x3 conv to 64 channels without skips");
@@ -648,6 +659,10 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         const double px = (double)B * H * W;
         rec = ctx->prof_open("conv_rows_rgbtail<bf16,64->64->rgb>", 2.0 * px * 9 * w.Cin * (w.Cout + ep.f2->c2),
                              px * w.Cin * esz + (double)rgbtail_partial_bytes(B, H, W), st);
+    } else if (ctx->prof && ep.pj) {
+        const double px = (double)B * H * W;
+        rec = ctx->prof_open("conv_rows_proj<bf16,k3,nt4+1x1>", 2.0 * px * (9.0 * w.Cin * w.Cout + (double)w.Cout * 16 * ep.pj->nblk),
+                             px * ((double)w.Cin * esz + (double)w.Cout * osz + (p.s1 ? (double)w.Cout * esz : 0.0) + (double)r * r * 16 * ep.pj->nblk * esz), st);
     } else if (ctx->prof) {
         char nm[96];
         snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.few ? "few" : w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),

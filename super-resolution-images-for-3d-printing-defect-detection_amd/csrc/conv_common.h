@@ -28,6 +28,11 @@ struct ConvParams {
     const char* f2w;    // the second conv's kernel as four 1 KiB MFMA A-fragments [t block][channel half] (rgbtail_pack_weights), or nullptr
     float* f2part;      // [B][tilesY][tilesX][(TH + 2) * 18][3] fp32 partial sums
     int f2c;            // the second conv's output channels
+    // conv_rows, fused 1x1 projection (conv_rows.hip, rows_epilogue_proj): beside its own 64-channel output the conv writes a 1x1 conv of
+    // that output (the f / g / h projections of the SelfAttention layer that follows, ESRGAN_model.py:48-56) into a second NHWC buffer
+    const char* pjw;    // [cout block < pj_nblk][channel half] 1 KiB MFMA A-fragments (proj_pack_weights), or nullptr
+    const float* pjbias;
+    char* pjout; int64_t pj_cs; int pj_coff; int pj_rs; int pj_nblk;
 };
 
 __device__ __forceinline__ int choff(int c, int ps) { return (c >> 5) * ps + (c & 31); }

@@ -118,6 +118,93 @@ __device__ __forceinline__ void rows_fuse2(const ConvParams& p, f32x4 (&acc)[R][
     }
 }
 
+// Fused 1x1 projection (64 couts per workgroup only).  SelfAttention (ESRGAN_model.py:48-56) opens with three 1x1 convs f / g / h of its
+// 64-channel input, 48 output channels together; as a kernel of its own that is a pure stream (read 128 B, write 96 B per pixel: 7 ms per
+// bench step).  The producing conv's epilogue has the pixel's 64 channels in registers in the MFMA's B-operand shape (rows_fuse2 above), so
+// the projection is 2 MFMAs per 16-channel block and output row, taken from the bf16-rounded values that are being stored -- the attention
+// input is read back by nobody but the attention's residual add.  With depth_to_space the cout tile of 64 is one sub-pixel's 64 channels,
+// so the same holds at the up-sampled resolution.  Main stores as in rows_epilogue_fast<PAIR>; NHWC views only (host-checked).
+template <int R, bool HAS1>
+__device__ __forceinline__ void rows_epilogue_proj(const ConvParams& p, f32x4 (&acc)[R][4], const f32x4 (&biasv)[4], int b, int y0, int x0, int ct,
+                                                   int wave, int lane, int px, int q) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int H = p.H, W = p.W, ox = x0 + px, oyw = y0 + wave * R;
+    const int rows = min(R, H - oyw);
+    if (rows <= 0) return;
+    const bool col_ok = ox < W;
+    const int oxc = col_ok ? ox : 0;
+    const float slope = p.act == SR_ACT_RELU ? 0.f : (p.act == SR_ACT_LRELU ? 0.2f : 1.f);
+    const float alpha = p.alpha, beta1 = p.beta1;
+    const int rr = p.r, nblk = p.pj_nblk;
+    const int si = rr > 1 ? ct / rr : 0, sj = rr > 1 ? ct - si * rr : 0;      // depth_to_space (DCR, Cd = 64): cout tile ct is sub-pixel (si, sj)
+    // main output: lanes q and q ^ 1 trade halves, an even-q lane stores 8 couts of block 2s, an odd-q lane 8 of block 2s + 1
+    const int lane_c = (q & 1) * 16 + 4 * (q & ~1);
+    const int64_t orow0 = ((int64_t)b * H + oyw) * rr + si;                   // output row of tile row 0; rows advance by rr
+    const int ooff = (ox * rr + sj) * (int)p.out_cs + p.out_coff + (rr > 1 ? 0 : ct * 64) + lane_c;
+    const int poff = (ox * rr + sj) * (int)p.pj_cs + p.pj_coff + 4 * q;
+    bf16x4 k1[HAS1 ? R : 1][4];
+    if (HAS1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = (int64_t)b * H + (oyw + (r < rows ? r : 0));
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                k1[r][n] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.s1) + row * p.s1_rs + (oxc * (int)p.s1_cs + choff(p.s1_coff + ct * 64 + n * 16 + 4 * q, p.s1_ps)));
+        }
+    }
+    bf16x8 wa[3][2];
+    f32x4 pjb[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) {
+        const int nbc = nb < nblk ? nb : 0;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) wa[nb][hf] = *reinterpret_cast<const bf16x8*>(p.pjw + ((nbc * 2 + hf) * 64 + lane) * 16);
+        pjb[nb] = *reinterpret_cast<const f32x4*>(p.pjbias + nbc * 16 + 4 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r >= rows) break;                                                  // wave-uniform
+        bf16x4 o[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x4 v = acc[r][n] + biasv[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope) * alpha;
+            if (HAS1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += beta1 * (float)k1[r][n][e];
+            }
+            o[n] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+        bf16_t* const orow = reinterpret_cast<bf16_t*>(p.out) + (orow0 + (int64_t)r * rr) * p.out_rs;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x2 au = __builtin_bit_cast(u32x2, o[2 * s]), cu = __builtin_bit_cast(u32x2, o[2 * s + 1]);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
+            const u32x4 ov = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+            if (col_ok) *reinterpret_cast<u32x4*>(orow + ooff + 32 * s) = ov;
+        }
+        // the projection of what was just stored: B fragment of channel half hf = the lane's 8 channels {16 (2 hf) + 4 q + e, 16 (2 hf + 1) + 4 q + e}
+        bf16x8 hb[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hb[hf][e] = o[2 * hf][e]; hb[hf][4 + e] = o[2 * hf + 1][e]; }
+        bf16_t* const prow = reinterpret_cast<bf16_t*>(p.pjout) + (orow0 + (int64_t)r * rr) * p.pj_rs;
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            if (nb >= nblk) break;                                             // uniform
+            f32x4 z = mma16(wa[nb][0], hb[0], pjb[nb]);
+            z = mma16(wa[nb][1], hb[1], z);
+            const bf16x4 zo = {(bf16_t)z[0], (bf16_t)z[1], (bf16_t)z[2], (bf16_t)z[3]};
+            if (col_ok) *reinterpret_cast<bf16x4*>(prow + poff + 16 * nb) = zo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NB16, int R, bool STAMP, bool FUSE2 = false>
 __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(ConvParams p) {
     constexpr int TH = 4 * R, TW = 16, PH = TH + 2, PW = TW + 2;
@@ -338,6 +425,14 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
         STAMP_AT(15);
         return;
     }
+    if constexpr (NB16 == 4) {
+        if (p.pjw) {                                                         // uniform; the host sends such a launch with at most skip 1 and no LDS skip
+            if (p.s1) rows_epilogue_proj<R, true>(p, acc, biasv, b, y0, x0, ct, wave, lane, px, q);
+            else rows_epilogue_proj<R, false>(p, acc, biasv, b, y0, x0, ct, wave, lane, px, q);
+            STAMP_AT(15);
+            return;
+        }
+    }
     if constexpr (SKIP_LDS_OK) if (skip_lds) {
         ConvParams pe = p;                                                  // the epilogue sees only the other skip, as skip 1
         if (p.skip_lds == 1) { pe.s1 = p.s2; pe.s1_cs = p.s2_cs; pe.s1_coff = p.s2_coff; pe.s1_ps = p.s2_ps; pe.s1_rs = p.s2_rs; pe.beta1 = p.beta2; }
@@ -469,6 +564,38 @@ int rgbtail_pack_weights(sr_ctx* ctx, const float* w2, const float* bias2, int c
     SR_HIP(ctx, hipMemcpy(w.bias, hb, sizeof hb, hipMemcpyHostToDevice));
     *out = w;
     return SR_OK;
+}
+
+// A fragment [nb][half]: lane l (cout i = l & 15 of block nb, k-quarter q = l >> 4), element j: W[channel 16 (2 half + (j >> 2)) + 4 q + (j & 3)][16 nb + i]
+int proj_pack_weights(sr_ctx* ctx, const float* w, const float* bias, int cout, ProjWeights* out) {
+    if (cout < 16 || cout > 48 || cout % 16 != 0) return ctx->fail(SR_ERR_INVALID, "fused projection: 16, 32 or 48 output channels");
+    const int nblk = cout / 16;
+    std::vector<uint16_t> host((size_t)nblk * 2 * 512, 0);
+    for (int nb = 0; nb < nblk; ++nb)
+        for (int hf = 0; hf < 2; ++hf)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * (2 * hf + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+                    host[((size_t)(nb * 2 + hf) * 64 + l) * 8 + j] = bf16_bits(w[(size_t)c * cout + 16 * nb + (l & 15)]);
+                }
+    ProjWeights pw;
+    pw.nblk = nblk;
+    pw.a = ctx->dalloc(host.size() * 2);
+    if (!pw.a) return SR_ERR_OOM;
+    pw.bias = static_cast<float*>(ctx->dalloc(sizeof(float) * cout));
+    if (!pw.bias) { ctx->dfree(pw.a); return SR_ERR_OOM; }
+    std::vector<float> hb(cout, 0.f);
+    if (bias) for (int i = 0; i < cout; ++i) hb[i] = bias[i];
+    SR_HIP(ctx, hipMemcpy(pw.a, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    SR_HIP(ctx, hipMemcpy(pw.bias, hb.data(), sizeof(float) * cout, hipMemcpyHostToDevice));
+    *out = pw;
+    return SR_OK;
+}
+
+void proj_free_weights(sr_ctx* ctx, ProjWeights* w) {
+    if (w->a) ctx->dfree(w->a);
+    if (w->bias) ctx->dfree(w->bias);
+    w->a = nullptr; w->bias = nullptr;
 }
 
 void rgbtail_free_weights(sr_ctx* ctx, RgbTailWeights* w) {

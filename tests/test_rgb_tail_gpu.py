@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def fused_ctx(ctx):
     yield ctx
-    ctx.set_fused(7, 0)
+    ctx.set_fused(15, 0)
 
 
 def kernels_of(ctx, fn):
@@ -127,3 +127,43 @@ def test_rgb_tail_falls_back_when_the_workspace_is_too_small(fused_ctx):
     assert not any("rgbtail" in k for k in ks)
     ref = M.esrgan_g_forward(x, w, 2, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=False)
     assert np.abs(y.cpu().numpy() - ref).max() <= 2e-2
+
+
+# ---- SelfAttention's f / g / h projections in the epilogue of the conv that produces the layer's input (rows_epilogue_proj) ----------
+
+PROJ_CASES = [
+    (2, 5, 7, 2),          # ragged tiles at both resolutions; the trunk conv carries its skip, the up-sampling conv depth_to_space
+    (1, 12, 16, 2),        # exactly one tile at the trunk resolution, 2 x 2 tiles after the shuffle
+    (2, 13, 20, 4),        # two up-sampling stages: attention after the first only
+]
+
+
+@pytest.mark.parametrize("case", PROJ_CASES)
+def test_attention_projections_in_the_producing_conv(fused_ctx, case):
+    from sr355.weights import condition_attention
+    ctx = fused_ctx
+    B, H, W, s = case
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=s, num_blocks=1, growth_channels=32, use_attention=True, ctx=ctx)
+    w = bf16_rounded(condition_attention(init_weights(m.layer_shapes(), seed=6200 + H)))
+    m.set_weights(w)
+    x = round_to_bf16(np.random.default_rng(H * W).uniform(-1, 1, (B, H, W, 3)).astype(np.float32))
+    xd = ctx.to_device(x, torch.bfloat16)
+    taps = ["self_attention_trunk_f", "self_attention_upsample_0_f", "trunk_conv", "upsample_0_conv"]
+    ctx.set_fused(7, 0)
+    (y0, t0), k0 = kernels_of(ctx, lambda: m.forward_with_taps(xd, taps))
+    ctx.set_fused(15, 0)
+    (y1, t1), k1 = kernels_of(ctx, lambda: m.forward_with_taps(xd, taps))
+    assert not any(k.startswith("conv_rows_proj") for k in k0) and any(k.startswith("conv_pw<bf16,k1,kg1,nt3>") for k in k0), k0
+    assert any(k.startswith("conv_rows_proj") for k in k1) and not any(k.startswith("conv_pw<bf16,k1,kg1,nt3>") for k in k1), k1
+    assert torch.equal(y1, m.forward(xd))
+    for n in ("trunk_conv", "upsample_0_conv"):                               # the conv's own output: same arithmetic, same stores
+        assert torch.equal(t0[n], t1[n]), n
+    for n in ("self_attention_trunk_f", "self_attention_upsample_0_f"):      # 48 channels f | g | h: same products, another fp32 summation order
+        a, b = t0[n].cpu().numpy(), t1[n].cpu().numpy()
+        assert a.shape[-1] == 48 and a.shape == b.shape
+        assert np.all(np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(a), 2.0 ** -10)), (n, float(np.abs(a - b).max()))
+        assert np.mean(a != b) < 0.02, (n, float(np.mean(a != b)))            # a flipped bf16 rounding here and there, no more
+    ref = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=True, bf16_storage=True)
+    e0 = np.abs(y0.float().cpu().numpy() - ref).max()
+    e1 = np.abs(y1.float().cpu().numpy() - ref).max()
+    assert e1 <= max(2.0 * e0, 2.0 ** -6), (float(e0), float(e1))
