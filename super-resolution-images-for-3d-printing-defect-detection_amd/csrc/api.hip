@@ -123,7 +123,7 @@ struct Op {
 };
 struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs)
 struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
-struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; };
+struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; int rows_head = 0; };   // rows_head: conv_pack_weights
 // two consecutive convs of a dense block that run as ONE kernel when the shape allows (dense_fused.hip): ops[first], ops[first + 1]
 struct ChainSpec { int conv_a = -1, conv_b = -1; int tail = 0; ChainWeights w; };
 // a 64-cout 3x3 conv followed by the 3x3 conv to the image's <= 3 channels: one kernel + a finishing pass when the shape allows (conv_rows.hip)
@@ -351,13 +351,18 @@ int build_vgg16(sr_model* m) {
     m->in_C = 3; m->out_C = nc; m->out_vec = true;
     static const int cfg[5][2] = {{2, 64}, {2, 128}, {3, 256}, {3, 512}, {3, 512}};
     const int x0 = b.buf(b.E());
-    m->bufs[x0].Cbuf = b.E();
+    // bf16: the RGB head runs on the row-sliding kernel over ONE zero-padded 32-channel chunk (64-cout workgroups, whole-line 16-byte stores)
+    // instead of the thin kernel (32-cout workgroups, 8-byte stores through the generic epilogue): 0.88 -> 0.4 ms per 1024 patches of 96 x 96.
+    // 29 of the chunk's 32 channels multiply zeros -- the layer is bound by its 64-channel output stream either way.
+    const bool head_rows = m->T == SR_DTYPE_BF16;
+    m->bufs[x0].Cbuf = head_rows ? 32 : b.E();
     Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
     int cur = x0, cin = 3;
     for (int blk = 0; blk < 5; ++blk) {
         for (int k = 0; k < cfg[blk][0]; ++k) {
             const int o = b.buf(cfg[blk][1], 1, blk);
             b.conv("block" + std::to_string(blk + 1) + "_conv" + std::to_string(k + 1), 3, cin, cfg[blk][1], {cur, 0}, {o, 0}, SR_ACT_RELU);
+            if (blk == 0 && k == 0 && head_rows) m->convs.back().rows_head = 1;
             cur = o; cin = cfg[blk][1];
         }
         const int pb = b.buf(cin, 1, blk + 1);
@@ -747,7 +752,7 @@ int sr_model_finalize(sr_model* m) {
         conv_free_weights(ctx, &c.w);
         std::vector<float> k, bias;
         gather(c, k, bias);
-        int rc = conv_pack_weights(ctx, k.data(), bias.data(), c.KS, c.Cin, c.Cout, m->T, &c.w);
+        int rc = conv_pack_weights(ctx, k.data(), bias.data(), c.KS, c.Cin, c.Cout, m->T, &c.w, c.rows_head);
         if (rc) return rc;
     }
     for (auto& ch : m->chains) {

@@ -146,8 +146,10 @@ struct ConvEpilogue {
 // 180-degree-rotated, channel-swapped form is wanted ([K,K,Cout,Cin]: the input-gradient conv of that layer); weights and bias land in
 // the context's arenas (valid until the next sr_conv2d_dev on the stream)
 int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias, int KS, int Cin, int Cout, int rot, ConvWeights* out, hipStream_t st);
+// rows_head = 1 (bf16 3x3 only): a conv whose Cin fits one 16-byte slice (an RGB head) is packed for the row-sliding kernel on one
+// zero-padded 32-channel chunk instead of the thin kernel -- the caller then provides a 32-channel input view
 int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS, int Cin, int Cout,
-                      int dtype, ConvWeights* out);
+                      int dtype, ConvWeights* out, int rows_head = 0);
 void conv_free_weights(sr_ctx* ctx, ConvWeights* w);
 // x view must expose >= w.CinP channels starting at coff (extra ones multiplied by zero weights).
 int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, int W,

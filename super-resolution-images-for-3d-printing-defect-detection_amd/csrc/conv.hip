@@ -394,7 +394,7 @@ int launch_fewcout(sr_ctx* ctx, const ConvParams& p, hipStream_t st) {
 // host side
 // ---------------------------------------------------------------------------------------------
 int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS, int Cin, int Cout, int dtype,
-                      ConvWeights* out) {
+                      ConvWeights* out, int rows_head) {
     if (dtype != SR_DTYPE_BF16 && dtype != SR_DTYPE_F32) return ctx->fail(SR_ERR_INVALID, "conv: dtype must be f32 or bf16");
     if (KS != 1 && KS != 3 && KS != 5 && KS != 9) return ctx->fail(SR_ERR_INVALID, "conv: kernel size must be 1,3,5 or 9");
     const int esz = dtype_size(dtype), E = 16 / esz;
@@ -404,10 +404,11 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
     const int nb = w.CoutP / 32;
     w.NT = (nb % 2 == 0) ? 2 : (nb % 3 == 0 ? 3 : 1);
     if (KS == 5 && !(Cin <= E)) w.NT = 1;   // 25 taps of weights: keep the LDS stage small
-    if (Cin <= E) w.NT = 1;                  // thin (RGB) inputs: one 32-cout block per workgroup (112 + 48 registers, 3 waves/SIMD);
+    const bool as_rows = rows_head && dtype == SR_DTYPE_BF16 && KS == 3;
+    if (Cin <= E && !as_rows) w.NT = 1;      // thin (RGB) inputs: one 32-cout block per workgroup (112 + 48 registers, 3 waves/SIMD);
                                              // re-reading the 3-channel input per cout block is cheap, 1 wave/SIMD at NT=3 was not (9x9: 1.8x)
     const int nct = nb / w.NT, ntap = KS * KS;
-    w.thin = Cin <= E;
+    w.thin = Cin <= E && !as_rows;
     // fp32, <= 4 couts, not thin: the VALU kernel (conv_fewcout_f32_kernel), weights [tap][CinP][4]
     w.few = (dtype == SR_DTYPE_F32 && Cout <= 4 && !w.thin && (KS == 3 || KS == 5)) ? 1 : 0;
     w.rows = (dtype == SR_DTYPE_BF16 && KS == 3 && !w.thin) ? 1 : 0;

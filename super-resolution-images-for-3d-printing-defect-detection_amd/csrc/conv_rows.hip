@@ -28,6 +28,7 @@
 // Prologue and epilogue are kept to a few hundred issue slots per wave (32-bit offsets from wave-uniform
 // 64-bit bases, branch-free activation, biases prefetched, skips loaded in bulk): in-kernel stamps showed
 // they, not the MFMAs, held the SIMDs in the first version.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -206,7 +207,7 @@ __device__ __forceinline__ void rows_epilogue_proj(const ConvParams& p, f32x4 (&
 }
 
 template <int NB16, int R, bool STAMP, bool FUSE2 = false>
-__global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(ConvParams p) {
+__global__ void __launch_bounds__(256, NB16 == 4 ? (R > 3 ? 2 : 3) : 4) conv3_rows_kernel(ConvParams p) {
     constexpr int TH = 4 * R, TW = 16, PH = TH + 2, PW = TW + 2;
     constexpr int NPIX = PH * PW;
     constexpr int NIN = NPIX * 4;                 // 16-byte units per chunk
@@ -447,11 +448,10 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? 3 : 4) conv3_rows_kernel(Conv
 
 // rows per wave: 16 x 16 output tiles, 12 x 16 for 64 couts per workgroup (see the occupancy note in the header);
 // 48/96/192-pixel patches tile exactly either way
-template <int NB16>
+template <int NB16, int R = (NB16 == 4 ? 3 : 4)>
 int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
-    constexpr int R = NB16 == 4 ? 3 : 4;
     constexpr int lds = (4 * R + 2) * 18 * 64 + 9 * NB16 * 1024 + NB16 * 64;
-    static_assert(NB16 != 4 || (4 * R * 16 * 36 * 4 <= lds && R == 3), "rows_fuse2 parks its tap channels in the tile's LDS; the finishing pass assumes 12 x 16 tiles");
+    static_assert(NB16 != 4 || 4 * R * 16 * 36 * 4 <= lds, "rows_fuse2 parks its tap channels in the tile's LDS");
     ConvParams p = p0;
     const int tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 4 * R - 1) / (4 * R);
@@ -469,7 +469,7 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
         SR_HIP(ctx, hipGetLastError());
         return SR_OK;
     }
-    if constexpr (NB16 == 4) {
+    if constexpr (NB16 == 4 && R == 3) {                     // (the finishing pass assumes 12 x 16 tiles)
         if (p.f2w) {
             if (nct != 1) return ctx->fail(SR_ERR_INVALID, "conv_rows: the fused RGB tail needs a 64-cout conv");
             auto kf = conv3_rows_kernel<NB16, R, false, true>;
@@ -628,7 +628,7 @@ int conv_rows_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams&
     switch (w.NT) {
         case 1: return launch_rows<1>(ctx, p, nct, st);
         case 2: return launch_rows<2>(ctx, p, nct, st);
-        case 4: return launch_rows<4>(ctx, p, nct, st);
+        case 4: return launch_rows<4>(ctx, p, nct, st);   // (round 3, measured again for the 64-channel layers of the output end: 24 x 16 tiles at two workgroups per CU, 256 registers: 3-5 % slower)
     }
     return ctx->fail(SR_ERR_INVALID, "conv_rows: unsupported cout block count");
 }

@@ -54,8 +54,19 @@ def device_trace(ctx, dtype, w, x, nb=NB, stages=STAGES):
     m.set_weights(w)
     td = torch.float32 if dtype == "f32" else torch.bfloat16
     y, taps = m.forward_with_taps(ctx.to_device(x, td), [dev for _, dev in stages])
-    y2 = m.forward(ctx.to_device(x, td))          # no taps, same buffers: the same image
-    assert torch.equal(y, y2)
+    y2 = m.forward(ctx.to_device(x, td))          # no taps, same buffers
+    if dtype == "f32":
+        assert torch.equal(y, y2)                 # the same kernels: the same image
+    else:
+        # a tap on final_conv1 makes final_conv1 / final_conv2 run as two kernels (the untapped forward folds the RGB conv into final_conv1's
+        # epilogue: another order of the fp32 additions), so the two bf16 images may differ by a flipped rounding here and there ...
+        d = (y.float() - y2.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 0.01, (float(d.max()), float((d > 0).float().mean()))
+        ctx.set_fused(15 & ~4, 0)                 # ... and are the same image when that pair runs as two kernels in both
+        try:
+            assert torch.equal(y, m.forward(ctx.to_device(x, td)))
+        finally:
+            ctx.set_fused(15, 0)
     return y.float().cpu().numpy(), {name: taps[dev].cpu().numpy() for name, dev in stages}
 
 
