@@ -200,7 +200,7 @@ def main():
                     help="round 1's weights: glorot without conditioning the attention logits (sr355.weights.condition_attention)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the other BASELINE rows (cfg3 training step, cfg4 streaming) that the N = 1 line carries beside the headline")
-    ap.add_argument("--fused", type=int, default=15,
+    ap.add_argument("--fused", type=int, default=31,
                     help="dense-block conv pairs run as one fused kernel: bit 0 conv4+conv5, bit 1 conv2+conv3, bit 2 final_conv2 inside final_conv1, bit 3 attention projections inside the producing conv (0 = layer by layer, for A/B runs)")
     args = ap.parse_args()
     if args.chunk <= 0:

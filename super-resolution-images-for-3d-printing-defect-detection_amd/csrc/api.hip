@@ -121,7 +121,7 @@ struct Op {
     int rgbtail = -1;                               // conv: first op of m->rgbtails[rgbtail] (the next op is the conv folded into this one's epilogue)
     int proj = -1;                                  // conv: the next op is the 1x1 projection m->projs[proj], which this conv's epilogue can compute
 };
-struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs)
+struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; int cells = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs); cells: small images may be packed in a CellGrid (common.h)
 struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
 struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; int rows_head = 0; };   // rows_head: conv_pack_weights
 // two consecutive convs of a dense block that run as ONE kernel when the shape allows (dense_fused.hip): ops[first], ops[first + 1]
@@ -150,6 +150,7 @@ struct sr_model {
     int in_C = 3, out_C = 3, out_mul = 1, out_shift = 0; bool out_vec = false;
     bool finalized = false;
     std::vector<size_t> bufcap;       // bytes currently allocated per workspace buffer (grow-only)
+    std::vector<CellGrid> grid_now;   // per workspace buffer: the packed layout its contents have now (gx = 0: plain NHWC)
     struct Tap { float* dst; int64_t cap; };
     std::unordered_map<int, Tap> taps; // diagnostic: op index -> device fp32 destination (sr_model_set_tap)
     std::vector<std::string> op_names; // per op, for sr_model_op_info
@@ -158,7 +159,7 @@ struct sr_model {
         for (size_t i = 0; i < params.size(); ++i) if (params[i].which == which && params[i].name == n) return (int)i;
         return -1;
     }
-    void free_bufs() { for (auto& p : bufp) { if (p) ctx->dfree(p); p = nullptr; } bufcap.assign(bufcap.size(), 0); }
+    void free_bufs() { for (auto& p : bufp) { if (p) ctx->dfree(p); p = nullptr; } bufcap.assign(bufcap.size(), 0); grid_now.assign(grid_now.size(), CellGrid{}); }
 };
 
 namespace {
@@ -363,9 +364,13 @@ int build_vgg16(sr_model* m) {
             const int o = b.buf(cfg[blk][1], 1, blk);
             b.conv("block" + std::to_string(blk + 1) + "_conv" + std::to_string(k + 1), 3, cin, cfg[blk][1], {cur, 0}, {o, 0}, SR_ACT_RELU);
             if (blk == 0 && k == 0 && head_rows) m->convs.back().rows_head = 1;
+            // block 5 works on (patch / 16)^2 images -- 6 x 6 for the reference's 96-pixel patches: its buffers may hold the batch packed in a
+            // CellGrid (sr_forward decides per call; the pool in front writes that layout, the pool behind reads it)
+            if (blk == 4 && m->T == SR_DTYPE_BF16) m->bufs[o].cells = 1;
             cur = o; cin = cfg[blk][1];
         }
         const int pb = b.buf(cin, 1, blk + 1);
+        if (blk == 3 && m->T == SR_DTYPE_BF16) m->bufs[pb].cells = 1;
         Op p; p.kind = OP_POOL; p.in = {cur, 0}; p.out = {pb, 0}; m->ops.push_back(p);
         cur = pb;
     }
@@ -451,14 +456,45 @@ inline void buf_hw(const BufSpec& b, int H, int W, int* h, int* w) {
 // later shape (no kernel ever writes a pad channel).
 // On an allocation failure every workspace buffer is released (after a device sync: earlier forwards may still be running on
 // them) so that a retry with a smaller batch starts from a clean slate instead of from the half-grown oversized set.
-int ensure_workspace(sr_model* m, int B, int H, int W, hipStream_t st) {
-    if (m->bufp.size() != m->bufs.size()) { m->bufp.assign(m->bufs.size(), nullptr); m->bufcap.assign(m->bufs.size(), 0); }
+// The packed layout of B images of h x w pixels (CellGrid, common.h), or gx = 0 where packing does not pay: the 64-cout kernel issues MFMAs for
+// 12 x 16 output tiles, so a plain image uses h w / (ceil(h / 12) 12 ceil(w / 16) 16) of them and the grid (h / (h + 1)) (gx w / 16).
+CellGrid cell_grid_for(int B, int h, int w, int Cbuf) {
+    CellGrid g;
+    if (h < 1 || w < 1 || w + 1 > 16) return g;
+    const int gx = 16 / (w + 1);
+    const double plain = (double)h * w / ((double)((h + 11) / 12 * 12) * ((w + 15) / 16 * 16));
+    const double packed = (double)h / (h + 1) * gx * w / 16.0;
+    if (packed < 1.3 * plain) return g;
+    const int64_t Hv = (int64_t)((B + gx - 1) / gx) * (h + 1), Wv = (int64_t)gx * (w + 1);
+    if (Hv * Wv * Cbuf >= ((int64_t)1 << 31)) return g;           // the conv kernels address an image with 32-bit offsets
+    g.gx = gx; g.ch = h + 1; g.cw = w + 1; g.Hv = (int)Hv; g.Wv = (int)Wv;
+    return g;
+}
+
+// use_cells: buffers marked `cells` adopt the packed layout for this forward where it pays (never with taps set: the tap copy reads plain NHWC)
+int ensure_workspace(sr_model* m, int B, int H, int W, hipStream_t st, bool use_cells) {
+    if (m->bufp.size() != m->bufs.size()) { m->bufp.assign(m->bufs.size(), nullptr); m->bufcap.assign(m->bufs.size(), 0); m->grid_now.assign(m->bufs.size(), CellGrid{}); }
     for (size_t i = 0; i < m->bufs.size(); ++i) {
         const BufSpec& b = m->bufs[i];
         size_t bytes;
+        CellGrid want;
         if (b.vec) bytes = (size_t)B * b.C * sizeof(float);
-        else { int h, w; buf_hw(b, H, W, &h, &w); bytes = (size_t)B * h * w * b.Cbuf * dtype_size(m->T) + 4096; }
-        if (bytes <= m->bufcap[i]) continue;
+        else {
+            int h, w; buf_hw(b, H, W, &h, &w);
+            bytes = (size_t)B * h * w * b.Cbuf * dtype_size(m->T) + 4096;
+            if (b.cells && use_cells) {
+                want = cell_grid_for(B, h, w, b.Cbuf);
+                if (want.gx) bytes = std::max(bytes, (size_t)want.Hv * want.Wv * b.Cbuf * dtype_size(m->T) + 4096);
+            }
+        }
+        if (bytes <= m->bufcap[i]) {
+            // the separators of a packed layout must be zeros: adopting one over other contents (a plain forward, another grid) clears the buffer
+            const CellGrid& have = m->grid_now[i];                  // (the cells of another batch size lie in the same places: nothing to clear)
+            if (want.gx && !(have.gx == want.gx && have.ch == want.ch && have.cw == want.cw && have.Wv == want.Wv)) SR_HIP(m->ctx, hipMemsetAsync(m->bufp[i], 0, m->bufcap[i], st));
+            m->grid_now[i] = want;
+            continue;
+        }
+        m->grid_now[i] = want;                                      // (a new allocation is zeroed below)
         if (m->bufp[i]) { SR_HIP(m->ctx, hipDeviceSynchronize()); m->ctx->dfree(m->bufp[i]); m->bufp[i] = nullptr; m->bufcap[i] = 0; }
         m->bufp[i] = m->ctx->dalloc(bytes);
         if (!m->bufp[i]) {
@@ -819,7 +855,8 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
     if (y_capacity < os[0] * os[1] * os[2] * os[3]) return ctx->fail(SR_ERR_CAPACITY, "output buffer too small");
     if (m->kind == SR_MODEL_VGG16 && (H < 32 || W < 32)) return ctx->fail(SR_ERR_INVALID, "VGG16 needs H,W >= 32");
     if (m->kind == SR_MODEL_VGG19_FEATURES && (H < 16 || W < 16)) return ctx->fail(SR_ERR_INVALID, "VGG19 features need H,W >= 16");
-    int rc = ensure_workspace(m, B, H, W, st);
+    const bool use_cells = m->taps.empty() && (ctx->chain_mask & 16) != 0;
+    int rc = ensure_workspace(m, B, H, W, st, use_cells);
     if (rc) return rc;
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     const int T = m->T;
@@ -881,6 +918,14 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 }
                 ConvEpilogue ep;
                 ep.act = op.act; ep.alpha = op.alpha; ep.clip01 = op.clip; ep.d2s_r = op.d2s;
+                int cB = B;
+                if (op.out.buf >= 0 && m->grid_now[op.in.buf].gx) {
+                    // both tensors hold the batch packed in the same CellGrid: one tall image to the kernel, separators never stored
+                    const CellGrid& g = m->grid_now[op.in.buf];
+                    if (!(m->grid_now[op.out.buf] == g) || op.skip1.buf >= 0 || op.skip2.buf >= 0 || op.d2s != 1)
+                        return ctx->fail(SR_ERR_STATE, "packed small-image layout: producer and consumer disagree");
+                    cB = 1; h = g.Hv; w = g.Wv; ep.cell_h = g.ch; ep.cell_w = g.cw;
+                }
                 if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff, m->bufs[op.skip1.buf].blk}; ep.beta1 = op.beta1; }
                 if (op.skip2.buf >= 0) { ep.skip2 = {m->bufp[op.skip2.buf], m->bufs[op.skip2.buf].Cbuf, op.skip2.coff, m->bufs[op.skip2.buf].blk}; ep.beta2 = op.beta2; }
                 if (op.proj >= 0 && (ctx->chain_mask & 8) && cs.w.rows && cs.w.NT == 4 && cs.w.Cout / (op.d2s * op.d2s) == 64 && cs.w.CoutP == cs.w.Cout &&
@@ -895,7 +940,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                     ep.out_f32 = io_dtype == SR_DTYPE_F32;
                     rc = conv_launch(ctx, cs.w, xin, B, h, w, y, m->out_C, 0, ep, st);
                 } else {
-                    rc = conv_launch(ctx, cs.w, xin, B, h, w, TensorView{m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, m->bufs[op.out.buf].blk}, ep, st);
+                    rc = conv_launch(ctx, cs.w, xin, cB, h, w, TensorView{m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, m->bufs[op.out.buf].blk}, ep, st);
                 }
                 break;
             }
@@ -916,7 +961,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 break;
             case OP_POOL:
                 rc = maxpool2_launch(ctx, T, m->bufp[op.in.buf], B, h, w, m->bufs[op.in.buf].C, m->bufs[op.in.buf].Cbuf, m->bufp[op.out.buf],
-                                     m->bufs[op.out.buf].Cbuf, st);
+                                     m->bufs[op.out.buf].Cbuf, st, m->grid_now[op.in.buf], m->grid_now[op.out.buf]);
                 break;
             case OP_GAP:
                 rc = gap_launch(ctx, T, m->bufp[op.in.buf], B, h * w, m->bufs[op.in.buf].C, m->bufs[op.in.buf].Cbuf,

@@ -55,7 +55,7 @@ struct sr_ctx {
     void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int cu_count();               // compute units of the device (queried once)
-    int chain_mask = 15;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue (sr_debug_set_fused; default all)
+    int chain_mask = 31;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid (sr_debug_set_fused; default all)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
 
@@ -127,7 +127,19 @@ struct ProjWeights {
     int nblk = 0;
 };
 
+// Packed layout of a batch of SMALL images (api.hip: VGG16 block 5).  A 6 x 6 image uses 19 % of the 12 x 16 output tile the 64-cout kernel
+// issues MFMAs for.  Image b instead sits in cell (b / gx, b % gx) of a grid of ch x cw = (h + 1) x (w + 1) cells whose last row / column is a
+// ZERO separator (the bottom / right padding of one image and the top / left padding of the next), and the whole batch is ONE image of Hv x Wv
+// pixels to the 3x3 kernel (gx = 2: 12 of 16 tile columns, 6 of 7 rows used).  The separators are zero because the buffer is zeroed when the
+// layout is adopted and nothing writes them: the conv epilogue skips them (ConvEpilogue::cell_h / cell_w), the pool writes image pixels only.
+// gx = 0: plain NHWC [B, H, W, C].
+struct CellGrid {
+    int gx = 0, ch = 0, cw = 0, Hv = 0, Wv = 0;
+    bool operator==(const CellGrid& o) const { return gx == o.gx && ch == o.ch && cw == o.cw && Hv == o.Hv && Wv == o.Wv; }
+};
+
 struct ConvEpilogue {
+    int cell_h = 0, cell_w = 0;           // conv_rows: do not store output rows y with y % cell_h == cell_h - 1 / columns x with x % cell_w == cell_w - 1 (CellGrid separators)
     const ProjWeights* pj = nullptr;      // conv_rows, 64 couts per output pixel, NHWC output: also write the 1x1 projection of the output to pj_out
     TensorView pj_out;                    // NHWC bf16 view at the conv's output resolution, >= 16 * nblk channels from coff
     const RgbTailWeights* f2 = nullptr;   // conv_rows, 64 couts, no skips: do not store this conv's output, write the following conv's partial sums to f2_part
@@ -200,7 +212,7 @@ int tap_copy_launch(sr_ctx* ctx, const void* src, int dtype, int blk, int64_t cs
 int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype,
                        int Cp, float mul, float add, hipStream_t st);
 int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y,
-                    int64_t y_cs, hipStream_t st);
+                    int64_t y_cs, hipStream_t st, CellGrid in_grid = CellGrid{}, CellGrid out_grid = CellGrid{});
 int gap_launch(sr_ctx* ctx, int dtype, const void* x, int B, int HW, int C, int64_t x_cs, float* y, hipStream_t st);
 // y[b,o] = act(sum_i x[b,i] w[i,o] + bias[o]); act: SR_ACT_LINEAR / _RELU / _LRELU, 100 = softmax over o, 101 = sigmoid.  fp32 in/out.
 int dense_launch(sr_ctx* ctx, const float* x, const float* w, const float* bias, int B, int In, int Out, int act,

@@ -625,6 +625,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.dbg = ctx->stamp_buf;
     p.f2w = nullptr; p.f2part = nullptr; p.f2c = 0;
     p.pjw = nullptr; p.pjbias = nullptr; p.pjout = nullptr; p.pj_cs = 0; p.pj_coff = 0; p.pj_rs = 0; p.pj_nblk = 0;
+    p.cell_h = ep.cell_h; p.cell_w = ep.cell_w;
     const int osz = p.out_f32 ? 4 : esz;
     bool vec = (y_cs % 4 == 0) && (y_coff % 4 == 0) && ((uintptr_t)y % (4 * osz) == 0) && (p.Cd % 4 == 0);
     if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);
@@ -639,6 +640,8 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         if (p.s2 && p.s2 == p.in && p.s2_cs == p.in_cs && p.s2_ps == p.in_ps && p.s2_coff == p.in_coff) { p.skip_lds = 2; p.skip_scale = p.beta2 / p.alpha; }
         else if (p.s1 && p.s1 == p.in && p.s1_cs == p.in_cs && p.s1_ps == p.in_ps && p.s1_coff == p.in_coff) { p.skip_lds = 1; p.skip_scale = p.beta1 / p.alpha; }
     }
+    if ((ep.cell_h || ep.cell_w) && !(w.rows && vec && w.Cout % 4 == 0 && ep.act != SR_ACT_TANH && r == 1 && !ep.pj && !ep.f2 && ep.cell_h >= 2 && ep.cell_w >= 2))
+        return ctx->fail(SR_ERR_INVALID, "conv: separator masks need the bf16 3x3 kernel's vector epilogue");
     if (ep.pj) {
         // every output pixel's 64 channels come from one workgroup: a 64-cout conv, or depth_to_space of 64-channel sub-pixels
         if (!(w.rows && w.NT == 4 && p.Cd == 64 && w.CoutP == w.Cout && !yv.blk && !p.s2 && !ep.clip01 && ep.act != SR_ACT_TANH && vec && !ep.f2 && ep.pj->a &&

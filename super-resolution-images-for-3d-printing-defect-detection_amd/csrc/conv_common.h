@@ -33,6 +33,7 @@ struct ConvParams {
     const char* pjw;    // [cout block < pj_nblk][channel half] 1 KiB MFMA A-fragments (proj_pack_weights), or nullptr
     const float* pjbias;
     char* pjout; int64_t pj_cs; int pj_coff; int pj_rs; int pj_nblk;
+    int cell_h, cell_w; // conv_rows fast epilogue: separator rows / columns of a CellGrid layout are not stored (0 = none)
 };
 
 __device__ __forceinline__ int choff(int c, int ps) { return (c >> 5) * ps + (c & 31); }

@@ -22,8 +22,9 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     const int oyw = y0 + wave * R;                         // first output row of this wave (wave-uniform)
     const int rows = min(R, H - oyw);                     // wave-uniform count of live rows
     if (rows <= 0) return;
-    const bool col_ok = ox < W;
-    const int oxc = col_ok ? ox : 0;
+    const int cell_h = p.cell_h, cell_w = p.cell_w;       // CellGrid separators (common.h): never stored, so they stay zero
+    const bool col_ok = ox < W && (cell_w == 0 || ox % cell_w != cell_w - 1);
+    const int oxc = ox < W ? ox : 0;
     // activation is branch-free: max(v, slope*v) with slope 1 (linear), 0 (relu), 0.2 (leaky relu)
     const float slope = p.act == SR_ACT_RELU ? 0.f : (p.act == SR_ACT_LRELU ? 0.2f : 1.f);
     const float alpha = p.alpha, beta1 = p.beta1, beta2 = p.beta2;
@@ -80,6 +81,7 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     for (int g = 0; g < RG; ++g) {
         const int r = r0 + g;
         if (r >= rows) break;                               // wave-uniform
+        if (cell_h != 0 && (oyw + r) % cell_h == cell_h - 1) continue;   // wave-uniform: a separator row
         f32x4 v[NB16];
 #pragma unroll
         for (int n = 0; n < NB16; ++n) {

@@ -34,7 +34,14 @@ __global__ void convert_pad_kernel(const void* x, int in_dt, int64_t npix, int C
 }
 
 // ---------------------------------------------------------------------------------- maxpool 2x2 (VALID, floor)
-__global__ void maxpool2_kernel(const void* x, int dt, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs) {
+// pixel index of (image b, row y, column x) of a batch of H x W images, plain or packed in a CellGrid (common.h); `rw` = pixels per buffer row
+__device__ __forceinline__ int64_t grid_pixel(const CellGrid& g, int64_t b, int y, int x, int H, int W, int* rw) {
+    if (g.gx == 0) { *rw = W; return (b * H + y) * W + x; }
+    *rw = g.Wv;
+    return ((b / g.gx) * g.ch + y) * (int64_t)g.Wv + (b % g.gx) * g.cw + x;
+}
+
+__global__ void maxpool2_kernel(const void* x, int dt, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs, CellGrid gi, CellGrid go) {
     const int Ho = H / 2, Wo = W / 2;
     const int64_t n = (int64_t)B * Ho * Wo * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -43,17 +50,18 @@ __global__ void maxpool2_kernel(const void* x, int dt, int B, int H, int W, int 
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int b = (int)(t / Ho);
-        const int64_t base = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * x_cs + c;
+        int rwi, rwo;
+        const int64_t base = grid_pixel(gi, b, 2 * oy, 2 * ox, H, W, &rwi) * x_cs + c;
         const float v = fmaxf(fmaxf(ld_dt(x, base, dt), ld_dt(x, base + x_cs, dt)),
-                              fmaxf(ld_dt(x, base + (int64_t)W * x_cs, dt), ld_dt(x, base + (int64_t)W * x_cs + x_cs, dt)));
-        st_dt(y, (((int64_t)b * Ho + oy) * Wo + ox) * y_cs + c, v, dt);
+                              fmaxf(ld_dt(x, base + (int64_t)rwi * x_cs, dt), ld_dt(x, base + (int64_t)rwi * x_cs + x_cs, dt)));
+        st_dt(y, grid_pixel(go, b, oy, ox, Ho, Wo, &rwo) * y_cs + c, v, dt);
     }
 }
 
 // bf16, 8 channels (16 B) per thread: the VGG16 pools move 2.9 GB per 1024 patches of 96 x 96; element by element that ran at ~1.5 TB/s.
 // max of bf16 values is exact in any order, so the result is the scalar kernel's bit for bit.
 __global__ void __launch_bounds__(256) maxpool2_bf16x8_kernel(const bf16_t* __restrict__ x, int B, int H, int W, int C8, int64_t x_cs, bf16_t* __restrict__ y,
-                                                              int64_t y_cs) {
+                                                              int64_t y_cs, CellGrid gi, CellGrid go) {
     const int Ho = H / 2, Wo = W / 2;
     const int64_t n = (int64_t)B * Ho * Wo * C8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -62,13 +70,14 @@ __global__ void __launch_bounds__(256) maxpool2_bf16x8_kernel(const bf16_t* __re
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int64_t b = t / Ho;
-        const bf16_t* s = x + ((b * H + 2 * oy) * W + 2 * ox) * x_cs + c;
+        int rwi, rwo;
+        const bf16_t* s = x + grid_pixel(gi, b, 2 * oy, 2 * ox, H, W, &rwi) * x_cs + c;
         const bf16x8 v00 = *reinterpret_cast<const bf16x8*>(s), v01 = *reinterpret_cast<const bf16x8*>(s + x_cs);
-        const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(s + (int64_t)W * x_cs), v11 = *reinterpret_cast<const bf16x8*>(s + (int64_t)W * x_cs + x_cs);
+        const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(s + (int64_t)rwi * x_cs), v11 = *reinterpret_cast<const bf16x8*>(s + (int64_t)rwi * x_cs + x_cs);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf(fmaxf((float)v00[e], (float)v01[e]), fmaxf((float)v10[e], (float)v11[e]));
-        *reinterpret_cast<bf16x8*>(y + ((b * Ho + oy) * Wo + ox) * y_cs + c) = o;
+        *reinterpret_cast<bf16x8*>(y + grid_pixel(go, b, oy, ox, Ho, Wo, &rwo) * y_cs + c) = o;
     }
 }
 
@@ -515,16 +524,17 @@ int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, i
     return SR_OK;
 }
 
-int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs, hipStream_t st) {
+int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y, int64_t y_cs, hipStream_t st, CellGrid gi,
+                    CellGrid go) {
     const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
     if (n <= 0) return ctx->fail(SR_ERR_INVALID, "maxpool: output would be empty");
     if (dtype == SR_DTYPE_BF16 && C % 8 == 0 && x_cs % 8 == 0 && y_cs % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) {
         hipLaunchKernelGGL(maxpool2_bf16x8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, st, static_cast<const bf16_t*>(x), B, H, W, C / 8, x_cs,
-                           static_cast<bf16_t*>(y), y_cs);
+                           static_cast<bf16_t*>(y), y_cs, gi, go);
         SR_HIP(ctx, hipGetLastError());
         return SR_OK;
     }
-    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, dtype, B, H, W, C, x_cs, y, y_cs);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, dtype, B, H, W, C, x_cs, y, y_cs, gi, go);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def fused_ctx(ctx):
     yield ctx
-    ctx.set_fused(15, 0)
+    ctx.set_fused(31, 0)
 
 
 def kernels_of(ctx, fn):
@@ -167,3 +167,29 @@ def test_attention_projections_in_the_producing_conv(fused_ctx, case):
     e0 = np.abs(y0.float().cpu().numpy() - ref).max()
     e1 = np.abs(y1.float().cpu().numpy() - ref).max()
     assert e1 <= max(2.0 * e0, 2.0 ** -6), (float(e0), float(e1))
+
+
+# ---- the VGG16 classifier's block 5 on a batch packed into one tall image (CellGrid, csrc/common.h; VGG16_model.py:57-97) --------------
+
+@pytest.mark.parametrize("patch", [96, 48, 128, 64])      # block-5 images 6 x 6 (two per tile row), 3 x 3 (four), 8 x 8 (one), 4 x 4 (three)
+def test_vgg16_block5_packed_batches(fused_ctx, patch):
+    """Every output pixel is the same sum in the same order whatever tile it falls into, so the packed path must give the plain path's
+    probabilities bit for bit: odd batches (a half-empty cell row), a batch after a larger one (stale cells beside live ones), a tapped
+    forward in between (plain layout over the packed buffers, then packed again: the separators are cleared)."""
+    ctx = fused_ctx
+    m = Model("vgg16", compute_dtype="bf16", num_classes=2, ctx=ctx)
+    w = bf16_rounded(init_weights(m.layer_shapes(), scheme="he_normal", seed=4100))
+    m.set_weights(w)
+    rng = np.random.default_rng(patch)
+    xs = [round_to_bf16(rng.uniform(0, 1, (n, patch, patch, 3)).astype(np.float32)) for n in (5, 2, 7, 1)]
+    ctx.set_fused(15, 0)
+    want = [m.forward(ctx.to_device(x, torch.bfloat16)).clone() for x in xs]
+    ctx.set_fused(31, 0)
+    got = [m.forward(ctx.to_device(x, torch.bfloat16)).clone() for x in xs]
+    for a, b in zip(want, got):
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    y_t, taps = m.forward_with_taps(ctx.to_device(xs[0], torch.bfloat16), ["block5_conv3"])       # plain layout for this call
+    assert torch.equal(y_t, want[0]) and taps["block5_conv3"].shape == (5, patch // 16, patch // 16, 512)
+    assert torch.equal(m.forward(ctx.to_device(xs[2], torch.bfloat16)), want[2])                  # packed again
+    ref = M.vgg16_classifier_forward(xs[0], w, dtype=np.float64)
+    assert np.max(np.abs(got[0].float().cpu().numpy() - ref)) <= 3e-2
