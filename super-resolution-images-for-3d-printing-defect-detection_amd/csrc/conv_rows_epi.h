@@ -81,7 +81,7 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
     for (int g = 0; g < RG; ++g) {
         const int r = r0 + g;
         if (r >= rows) break;                               // wave-uniform
-        if (cell_h != 0 && (oyw + r) % cell_h == cell_h - 1) continue;   // wave-uniform: a separator row
+        const bool row_ok = cell_h == 0 || (oyw + r) % cell_h != cell_h - 1;   // wave-uniform: a separator row is computed like any other, not stored
         f32x4 v[NB16];
 #pragma unroll
         for (int n = 0; n < NB16; ++n) {
@@ -112,12 +112,12 @@ __device__ __forceinline__ void rows_epilogue_fast(const ConvParams& p, f32x4 (&
                 const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
                 const u32x4 o = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
-                if (live[s]) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + base + loff[s]) = o;
+                if (live[s] && row_ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + base + loff[s]) = o;
             } else if (of32) {
-                if (live[s]) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + base + loff[s]) = v[s];
+                if (live[s] && row_ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + base + loff[s]) = v[s];
             } else {
                 const bf16x4 o = {(bf16_t)v[s][0], (bf16_t)v[s][1], (bf16_t)v[s][2], (bf16_t)v[s][3]};
-                if (live[s]) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + base + loff[s]) = o;
+                if (live[s] && row_ok) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + base + loff[s]) = o;
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // finish a row before starting the next: keeps the register peak at one row of temporaries
