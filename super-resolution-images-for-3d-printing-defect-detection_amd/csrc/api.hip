@@ -268,7 +268,9 @@ int build_esrgan(sr_model* m) {
     m->in_C = C; m->out_C = C; m->out_mul = s;
     const int CC = 64 + 4 * G;
     const int x0 = b.buf(b.E());
-    m->bufs[x0].Cbuf = b.E();
+    // bf16: the RGB head on the row-sliding kernel over one zero-padded 32-channel chunk (as in build_vgg16: whole-line stores, 64 couts per workgroup)
+    const bool head_rows = m->T == SR_DTYPE_BF16;
+    m->bufs[x0].Cbuf = head_rows ? 32 : b.E();
     const int trunk = b.buf(64);
     int cat[3] = {b.buf(CC), b.buf(CC), b.buf(CC)};
     // The concat buffers are only ever touched by convs (written by initial_conv / the dense convs, read by the bf16 3x3
@@ -277,6 +279,7 @@ int build_esrgan(sr_model* m) {
         for (int i = 0; i < 3; ++i) m->bufs[cat[i]].blk = 1;
     Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
     b.conv("initial_conv", 3, C, 64, {x0, 0}, {trunk, 0});
+    if (head_rows) m->convs.back().rows_head = 1;
     if (m->bufs[cat[0]].blk) {        // the trunk input also goes into the first concat buffer: a layout-changing copy of 64 channels
         Op t; t.kind = OP_TOBLK; t.in = {trunk, 0}; t.out = {cat[0], 0}; m->ops.push_back(t);
     } else {

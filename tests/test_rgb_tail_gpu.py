@@ -156,13 +156,20 @@ def test_attention_projections_in_the_producing_conv(fused_ctx, case):
     assert not any(k.startswith("conv_rows_proj") for k in k0) and any(k.startswith("conv_pw<bf16,k1,kg1,nt3>") for k in k0), k0
     assert any(k.startswith("conv_rows_proj") for k in k1) and not any(k.startswith("conv_pw<bf16,k1,kg1,nt3>") for k in k1), k1
     assert torch.equal(y1, m.forward(xd))
-    for n in ("trunk_conv", "upsample_0_conv"):                               # the conv's own output: same arithmetic, same stores
-        assert torch.equal(t0[n], t1[n]), n
-    for n in ("self_attention_trunk_f", "self_attention_upsample_0_f"):      # 48 channels f | g | h: same products, another fp32 summation order
-        a, b = t0[n].cpu().numpy(), t1[n].cpu().numpy()
-        assert a.shape[-1] == 48 and a.shape == b.shape
-        assert np.all(np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(a), 2.0 ** -10)), (n, float(np.abs(a - b).max()))
-        assert np.mean(a != b) < 0.02, (n, float(np.mean(a != b)))            # a flipped bf16 rounding here and there, no more
+    assert torch.equal(t0["trunk_conv"], t1["trunk_conv"])                   # the conv's own output: same arithmetic, same stores
+    # (upsample_0_conv sits behind the trunk attention, whose projections may differ by a flipped bf16 rounding: close, not identical)
+    a, b = t0["upsample_0_conv"].cpu().numpy(), t1["upsample_0_conv"].cpu().numpy()
+    assert np.abs(a - b).max() <= 2.0 ** -6 * max(1.0, np.abs(a).max()), float(np.abs(a - b).max())
+    # the trunk attention's 48 channels f | g | h come from bit-identical inputs: same products, another fp32 summation order -- a flipped bf16
+    # rounding here and there, no more
+    a, b = t0["self_attention_trunk_f"].cpu().numpy(), t1["self_attention_trunk_f"].cpu().numpy()
+    assert a.shape[-1] == 48 and a.shape == b.shape
+    assert np.all(np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(a), 2.0 ** -10)), float(np.abs(a - b).max())
+    assert np.mean(a != b) < 0.02, float(np.mean(a != b))
+    # the second attention's inputs already differ by such flips (they sit behind the first): close
+    a, b = t0["self_attention_upsample_0_f"].cpu().numpy(), t1["self_attention_upsample_0_f"].cpu().numpy()
+    assert a.shape[-1] == 48 and a.shape == b.shape
+    assert np.abs(a - b).max() <= 2.0 ** -5 * max(1.0, np.abs(a).max()), float(np.abs(a - b).max())
     ref = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=True, bf16_storage=True)
     e0 = np.abs(y0.float().cpu().numpy() - ref).max()
     e1 = np.abs(y1.float().cpu().numpy() - ref).max()

@@ -5,7 +5,8 @@ MI355X_MICROARCH.md section HBM) + WRITE_SIZE * 1024, averaged over the launches
 the LAST forward of the probe.  Keys are bench.py's kernel names."""
 import csv, glob, json, sys
 
-NAMES = {"conv3_rows_kernel<1,": "conv_rows<bf16,k3,kg1,nt1>", "conv3_rows_kernel<2,": "conv_rows<bf16,k3,kg1,nt2>",
+NAMES = {"conv3_rows_kernel<4,3,false,true>": "conv_rows_rgbtail<bf16,64->64->rgb>",      # first match wins: the fused RGB tail before the plain 64-cout kernel
+         "conv3_rows_kernel<1,": "conv_rows<bf16,k3,kg1,nt1>", "conv3_rows_kernel<2,": "conv_rows<bf16,k3,kg1,nt2>",
          "conv3_rows_kernel<4,": "conv_rows<bf16,k3,kg1,nt4>",
          "chain2_kernel<5,2,4,1,": "dense_tail_fused<bf16,conv4+conv5>", "chain2_kernel<3,2,2,0,": "dense_pair_fused<bf16>"}
 
@@ -34,6 +35,7 @@ for k in range(last - n_per_fwd + 1, last + 1):
                 a = agg.setdefault(nm, [0, 0.0])
                 a[0] += 1
                 a[1] += 2.0 * fv * 1024 + write[k][2] * 1024
+            break
 res = {nm: a[1] / a[0] for nm, a in agg.items()}
 res["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB -> B), separate rocprofv3 --pmc passes over tools/probe_trunk.py "
                 f"{sys.argv[4]} patches 48x48 (trunk convs only, no attention); averaged over the launches of one forward")
