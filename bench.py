@@ -356,6 +356,7 @@ def main():
                                    "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
                        "tiles_this_rank": n_mine, "global_batch": global_tiles, "patches_per_forward": min(args.chunk, 441 * max(n_mine, 1)),
                        "tiles_per_call": args.tiles_per_call, "fused_dense_pairs_mask": args.fused,
+                       "fused_mask_bits": "1 conv4+conv5, 2 conv2+conv3, 4 final_conv2 inside final_conv1, 8 attention projections inside the producing conv, 16 packed small-image batches (classifier)",
                        "distinct_tiles": 4, "tile_of_batch_index": "batch tile t is synthetic tile t % 4 (4 distinct 512x512 tiles, each 4 times; nothing is cached between tiles)",
                        "world_size_env": world, "world_size_process_group": group_world, "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
                        "parallelism": f"dp{group_world} (tile shards, metric all-reduce only)"},
