@@ -902,6 +902,11 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                         break;
                     }
                 }
+                if ((ctx->chain_mask & 32) && op.chain < 0 && op.act == SR_ACT_RELU && op.alpha == 1.f && op.skip1.buf < 0 && op.skip2.buf < 0 && op.d2s == 1 && !op.clip &&
+                    op.out.buf == op.in.buf && op.in.coff == 0 && op.out.coff == 64 && conv1_stream_supported(cs.w, xin, w)) {
+                    rc = conv1_stream_launch(ctx, cs.w, xin, B, h, w, st);           // conv1 of a dense block: the streaming kernel
+                    break;
+                }
                 if (op.rgbtail >= 0 && (ctx->chain_mask & 4) && m->taps.count((int)oi) == 0 && cs.w.rows && cs.w.NT == 4 && cs.w.Cout == 64 &&
                     op.skip1.buf < 0 && op.skip2.buf < 0 && op.d2s == 1 && !op.clip && op.act != SR_ACT_TANH && op.out.buf >= 0 &&
                     (int64_t)m->bufcap[op.out.buf] >= rgbtail_partial_bytes(B, h, w)) {

@@ -55,7 +55,7 @@ struct sr_ctx {
     void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int cu_count();               // compute units of the device (queried once)
-    int chain_mask = 31;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid (sr_debug_set_fused; default all)
+    int chain_mask = 63;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid, bit 5: conv1 of a dense block on the streaming kernel (sr_debug_set_fused; default all)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
 
@@ -190,6 +190,9 @@ struct ChainWeights {
 int chain_pack_weights(sr_ctx* ctx, const float* wa_hwio, const float* ba, const float* wb_hwio, const float* bb, int ext, int nb0, int nb1, ChainWeights* out);
 void chain_free_weights(sr_ctx* ctx, ChainWeights* w);
 bool chain_supported(const ChainWeights& w, const TensorView& in, int W);
+// conv1 of a dense block (64 -> 32, writes chunk 2 of the row-blocked buffer it reads) as a streaming line-buffer kernel (dense_fused.hip)
+bool conv1_stream_supported(const ConvWeights& w, const TensorView& in, int W);
+int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st);
 int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H, int W, TensorView out, TensorView skip_o, float alpha, float beta_x,
                  float beta_o, hipStream_t st);
 

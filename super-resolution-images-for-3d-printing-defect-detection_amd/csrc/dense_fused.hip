@@ -645,6 +645,173 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     }
 }
 
+// ==================================================================================================================================
+// conv1 of a dense block (64 -> 32 channels, ESRGAN_model.py:230-233) as a streaming kernel of its own.
+//
+// It is the one HBM-bound conv of the block (192 FLOP per byte against a ridge of 312): on the tile kernel a workgroup lives ~11 us for ~1 us of
+// MFMAs -- load a tile, wait, multiply, store -- and four of them per CU keep 4.7 TB/s in flight.  Here the rows of a workgroup's range of the
+// global row stream (as chain2_kernel: images top to bottom, a zero separator row after each) flow through FOUR staging buffers -- two 32-channel
+// chunks x two 8-row steps, 120 KiB -- filled by four loader waves 1.5 steps ahead of the eight compute waves, while the conv's whole 36 KiB of weights
+// sit in LDS for the life of the kernel (no weight slots, no ring, one barrier per chunk).  Output rows leave straight from the accumulators: with 32
+// couts a lane pair's permlane16_swap gives every lane 16 contiguous bytes and a column group's 64 lanes one contiguous KiB of the row-blocked row.
+// Weights: the row-sliding kernel's packed layout (conv.hip: [chunk][tap = ky * 3 + kx][cout block][lane][8]) as it is.
+struct Conv1Params {
+    const char* in; int in_nch;        // row-blocked concat buffer: reads chunks 0, 1, writes chunk 2
+    const char* w;                     // 36 KiB packed weights (ConvWeights of the 64 -> 32 conv)
+    const float* bias;                 // [32]
+    const char* zero;                  // zero page
+    int B, H;
+    int rows_per_wg; unsigned magic;
+};
+
+constexpr int C1_NSTG = 10;            // staged rows per chunk and step: stream rows [8s - 1, 8s + 9)
+constexpr int C1_STGB = C1_NSTG * ROWB;
+constexpr int C1_NSB = 4;
+constexpr int C1_WBYTES = 2 * 9 * 2 * 1024;
+constexpr int C1_LDS = C1_NSB * C1_STGB + C1_WBYTES + 32 * 4;
+static_assert(C1_LDS <= 160 * 1024, "LDS budget");
+
+__global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4) conv1_stream_kernel(Conv1Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const stg = smem;
+    char* const lw = smem + C1_NSB * C1_STGB;
+    float* const lbias = reinterpret_cast<float*>(lw + C1_WBYTES);
+    constexpr int NTHR = (NCOMP + NLOAD) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, Hp1 = H + 1;
+    const int T = p.B * Hp1;
+    const int R0 = blockIdx.x * p.rows_per_wg, R1 = min(T, R0 + p.rows_per_wg);
+    if (R0 >= R1) return;
+    const int nsteps = (R1 - R0 + 7) >> 3;                         // local stream row g = global row R0 + g
+    const int nchunks = 2 * nsteps;                                // (step, chunk) units in order
+
+    // one-time: the whole conv's weights and the biases
+    for (int u = tid; u < C1_WBYTES / 16; u += NTHR) *reinterpret_cast<f32x4*>(lw + u * 16) = *reinterpret_cast<const f32x4*>(p.w + u * 16);
+    if (tid < 32) lbias[tid] = p.bias[tid];
+
+    auto row_of = [&](int g, int& img, int& y) -> bool {          // local stream row -> (image, row); false: separator / outside the stream
+        const int gg = R0 + g;
+        if (gg < 0 || gg >= T) return false;
+        img = (int)__umulhi((unsigned)gg, p.magic);
+        y = gg - img * Hp1;
+        return y < H;
+    };
+    if (wave >= NCOMP) {
+        // ------------------------------------------------------------------------------------------------ loader waves
+        // unit k = (step k / 2, chunk k % 2) goes to buffer k % 4.  Loader LW stages rows LW, LW + 4 and (LW < 2) 8 + LW of every unit: three
+        // 1 KiB pieces per row from one address.  Schedule per barrier k (the barrier that lets the compute waves start unit k): issue unit
+        // k + 3 (its buffer was released by the barrier before: unit k - 1 is done), then wait until unit k + 1 has landed = all but this
+        // loader's pieces of units k + 2 and k + 3.
+        const int lwr = wave - NCOMP;
+        const int lsrc = 64 * (lane >> 2) + 16 * ((lane & 3) ^ (2 * ((lane >> 4) & 1)));
+        auto loader = [&](auto LWc) {
+            constexpr int LW = decltype(LWc)::value;
+            constexpr int NROWS = LW < 2 ? 3 : 2, NP = 3 * NROWS;
+            auto stage_unit = [&](int k) {                         // every unit is issued, also those past the end (zero page: nobody reads them)
+                const int s2 = k >> 1, c = k & 1;
+                char* const sdst = stg + (k % C1_NSB) * C1_STGB;
+                static_for<NROWS>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value == 0 ? LW : decltype(Jc)::value == 1 ? LW + 4 : 8 + LW;
+                    int img, y;
+                    const bool real = k < nchunks && row_of(8 * s2 - 1 + j, img, y);
+                    const char* src = (real ? p.in + (((int64_t)img * H + y) * p.in_nch + c) * ROWB : p.zero) + lsrc;
+                    const auto gs = (const __attribute__((address_space(1))) void*)src;
+                    const auto ld = (__attribute__((address_space(3))) void*)(sdst + j * ROWB);
+                    // (the nt policy for the rows no later step re-reads, which keeps the fused pairs' halo rows in L2, measured 2 % slower here)
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
+                    __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
+                });
+            };
+            stage_unit(0); stage_unit(1); stage_unit(2);
+            for (int k = 0; k < nchunks; ++k) {
+                if (k == 0) wait_imm<2 * NP>();                    // unit 0 has landed (units 1, 2 may fly)
+                __builtin_amdgcn_s_barrier();                      // compute may start unit k; unit k - 1's buffer is free
+                stage_unit(k + 3);
+                wait_imm<2 * NP>();                                // unit k + 1 has landed
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        // the one-time LDS writes above are published by the first barrier (lgkmcnt first)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lwr == 0) loader(std::integral_constant<int, 0>{});
+        else if (lwr == 1) loader(std::integral_constant<int, 1>{});
+        else if (lwr == 2) loader(std::integral_constant<int, 2>{});
+        else loader(std::integral_constant<int, 3>{});
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------------- compute waves
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own share of the weight copy
+    int offk[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int c = px + kx - 1;
+        offk[kx] = 64 * c + 16 * (q ^ (2 * ((c >> 2) & 1)));
+    }
+    const bool edge_l = px == 0, edge_r = px == 15;
+    const int off_l = edge_l ? offk[1] : offk[0];
+    const int off_r = edge_r ? offk[1] : offk[2];
+    typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+    for (int s = 0; s < nsteps; ++s) {
+        f32x4 acc[2][3];
+        // (the biases were written before the first barrier below)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = 2 * s + c;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c == 0) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) acc[n][cg] = b;
+                }
+            }
+            const char* const sb = stg + (k % C1_NSB) * C1_STGB + wave * ROWB;       // staged row j = w + ky
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                bf16x8 wf[3][2];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) wf[ky][n] = *reinterpret_cast<const bf16x8*>(lw + (((c * 9) + ky * 3 + kx) * 2 + n) * 1024 + lane * 16);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) {
+                        const int off = (kx == 0 && cg == 0) ? off_l : (kx == 2 && cg == 2) ? off_r : offk[kx];
+                        bf16x8 x = *reinterpret_cast<const bf16x8*>(sb + ky * ROWB + cg * 1024 + off);
+                        if ((kx == 0 && cg == 0 && edge_l) || (kx == 2 && cg == 2 && edge_r)) x = bf16x8{};
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[n][cg] = mma16(wf[ky][n], x, acc[n][cg]);
+                    }
+                }
+            }
+        }
+        // ---- epilogue: ReLU -> bf16 -> chunk 2 of the row, 16 contiguous bytes per lane (lanes q, q ^ 1 trade halves)
+        int img, y;
+        const int g = 8 * s + wave;
+        if (g < R1 - R0 && row_of(g, img, y)) {
+            char* const grow = const_cast<char*>(p.in) + (((int64_t)img * H + y) * p.in_nch + 2) * ROWB;
+            const int lane_b = 64 * px + 2 * ((q & 1) * 16 + 4 * (q & ~1));
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) {
+                bf16x4 o[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    o[n] = bf16x4{(bf16_t)fmaxf(acc[n][cg][0], 0.f), (bf16_t)fmaxf(acc[n][cg][1], 0.f), (bf16_t)fmaxf(acc[n][cg][2], 0.f), (bf16_t)fmaxf(acc[n][cg][3], 0.f)};
+                const u32x2c au = __builtin_bit_cast(u32x2c, o[0]), cu = __builtin_bit_cast(u32x2c, o[1]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
+                const u32x4 ov = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+                __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(grow + cg * 1024 + lane_b));
+            }
+        }
+    }
+}
+
 uint16_t bf16_host(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -722,6 +889,46 @@ void chain_free_weights(sr_ctx* ctx, ChainWeights* w) {
     if (w->w) ctx->dfree(w->w);
     if (w->bias) ctx->dfree(w->bias);
     w->w = nullptr; w->bias = nullptr;
+}
+
+// conv1 of a dense block on the streaming kernel: `in` is the block's row-blocked concat buffer (reads channels [0, 64), writes [64, 96)),
+// `w` the conv's ordinary packed weights (row-sliding layout, 64 -> 32)
+bool conv1_stream_supported(const ConvWeights& w, const TensorView& in, int W) {
+    return w.w != nullptr && w.rows && w.dtype == SR_DTYPE_BF16 && w.KS == 3 && w.Cin == 64 && w.Cout == 32 && w.NT == 2 && w.nchunks == 2 && W == 48 && in.blk &&
+           in.coff == 0 && in.cs % 32 == 0 && in.cs >= 96;
+}
+
+int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st) {
+    if (!conv1_stream_supported(w, in, W)) return ctx->fail(SR_ERR_INVALID, "streaming conv1: needs a 64 -> 32 bf16 3x3 conv on a 48-pixel-wide row-blocked buffer");
+    if (B <= 0 || H <= 0) return ctx->fail(SR_ERR_INVALID, "streaming conv1: empty tensor");
+    if (!ctx->zero_page) {
+        ctx->zero_page = ctx->dalloc(ZERO_PAGE_BYTES);
+        if (!ctx->zero_page) return SR_ERR_OOM;
+        SR_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, ZERO_PAGE_BYTES, st));
+    }
+    int ncu = ctx->cu_count();
+    if (ctx->chain_max_wgs > 0 && ctx->chain_max_wgs < ncu) ncu = ctx->chain_max_wgs;
+    Conv1Params p;
+    p.in = static_cast<const char*>(in.p); p.in_nch = (int)(in.cs / 32);
+    p.w = static_cast<const char*>(w.w); p.bias = w.bias; p.zero = static_cast<const char*>(ctx->zero_page);
+    p.B = B; p.H = H;
+    const int64_t T = (int64_t)B * (H + 1);
+    if ((T + 16) * (int64_t)(H + 1) * (H + 1) >= (1ll << 32)) return ctx->fail(SR_ERR_INVALID, "streaming conv1: stream too long");
+    const int nwg_target = (int)std::max<int64_t>(1, std::min<int64_t>(ncu, (T + 15) / 16));
+    p.rows_per_wg = (int)((T + nwg_target - 1) / nwg_target);
+    const int nwg = (int)((T + p.rows_per_wg - 1) / p.rows_per_wg);
+    p.magic = (unsigned)(((1ull << 32) + (unsigned)H) / (unsigned)(H + 1));
+    int rec = -1;
+    if (ctx->prof) {
+        const double px = (double)B * H * W;
+        rec = ctx->prof_open("dense_conv1_stream<bf16,64->32>", 2.0 * px * 9.0 * 64 * 32, px * 2.0 * (64 + 32), st);
+    }
+    auto k = conv1_stream_kernel;
+    if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), C1_LDS)) return rc;
+    hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), C1_LDS, st, p);
+    ctx->prof_close(rec, st);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
 }
 
 bool chain_supported(const ChainWeights& w, const TensorView& in, int W) {

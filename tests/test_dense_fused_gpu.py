@@ -24,7 +24,7 @@ def rel_l2(a, b):
 @pytest.fixture()
 def fused_ctx(ctx):
     yield ctx
-    ctx.set_fused(31, 0)
+    ctx.set_fused(63, 0)
 
 
 CASES = [
@@ -42,7 +42,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("mask", [1, 2, 3])
+@pytest.mark.parametrize("mask", [1, 2, 3, 32, 35])       # bit 5: conv1 of every dense block on the streaming kernel
 def test_fused_pairs_match_layer_by_layer_and_oracle(fused_ctx, case, mask):
     ctx = fused_ctx
     B, H, cap = case
@@ -52,7 +52,8 @@ def test_fused_pairs_match_layer_by_layer_and_oracle(fused_ctx, case, mask):
     m.set_weights(w)
     x = round_to_bf16(np.random.default_rng(B * 100 + H).uniform(-1, 1, (B, H, 48, 3)).astype(np.float32))
     xd = ctx.to_device(x, torch.bfloat16)
-    names = [f"rrdb_{b}_dense{d}_conv5" for b in range(nb) for d in (1, 2, 3)] + ["rrdb_0_dense1_conv3", "rrdb_1_dense2_conv2"]
+    names = [f"rrdb_{b}_dense{d}_conv5" for b in range(nb) for d in (1, 2, 3)] + ["rrdb_0_dense1_conv3", "rrdb_1_dense2_conv2", "rrdb_0_dense1_conv1",
+                                                                                 "rrdb_1_dense3_conv1"]
     ctx.set_fused(0, 0)
     y0, t0 = m.forward_with_taps(xd, names)
     ctx.set_fused(mask, cap)
@@ -99,9 +100,12 @@ def test_fused_tail_exact_integers(fused_ctx):
     xd = ctx.to_device(x, torch.bfloat16)
     names = ["rrdb_0_dense1_conv2", "rrdb_0_dense1_conv3", "rrdb_0_dense1_conv5", "rrdb_0_dense2_conv5", "rrdb_0_dense3_conv5"]
     ctx.set_fused(0, 0)
-    _, t0 = m.forward_with_taps(xd, names)
-    ctx.set_fused(3, 2)
-    _, t1 = m.forward_with_taps(xd, names)
+    _, t0 = m.forward_with_taps(xd, names + ["rrdb_0_dense1_conv1", "rrdb_0_dense2_conv1"])
+    ctx.set_fused(35, 2)
+    _, t1 = m.forward_with_taps(xd, names + ["rrdb_0_dense1_conv1", "rrdb_0_dense2_conv1"])
+    for n in ("rrdb_0_dense1_conv1", "rrdb_0_dense2_conv1"):                  # the streaming conv1 kernel: integers again for dense1, same roundings for dense2
+        a, b = t0[n].cpu().numpy(), t1[n].cpu().numpy()
+        assert (np.array_equal(a, b) if "dense1" in n else np.abs(a - b).max() <= 2.0 ** -7 * max(1.0, np.abs(a).max())), (n, float(np.abs(a - b).max()))
     # conv outputs are integers; x + 0.2*conv5 is not, but both paths round the same fp32 value
     for n in names[:2]:
         a, b = t0[n].cpu().numpy(), t1[n].cpu().numpy()

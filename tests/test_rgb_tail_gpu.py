@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def fused_ctx(ctx):
     yield ctx
-    ctx.set_fused(31, 0)
+    ctx.set_fused(63, 0)
 
 
 def kernels_of(ctx, fn):
