@@ -37,6 +37,11 @@ def test_fused_dense_kernels_use_no_scratch():
                         "--scratch-only"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "9 kernels checked" in r.stdout and " 0 problems" in r.stdout
+    # the streaming conv1 kernel (same roles, same counted waits)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch_hazards.py"), "--source", src, "--match", "conv1_stream_kernel",
+                        "--scratch-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "1 kernels checked" in r.stdout and " 0 problems" in r.stdout
 
 
 def test_checker_flags_a_register_touched_under_an_outstanding_load():

@@ -118,3 +118,40 @@ def test_model_catches_a_wrong_wait():
                 simulate(5, 2, 4, 1, lw, nsteps=4)
     finally:
         Plan.wait_n = real
+
+
+# ---- conv1_stream_kernel (csrc/dense_fused.hip): units k = (step k // 2, chunk k % 2) through four staging buffers ----------------------------
+
+def _conv1_loader_replay(lw, nunits):
+    """The loader loop of conv1_stream_kernel restated: prologue units 0..2; per barrier k: [k == 0: wait all but 2 NP]; barrier; issue unit
+    k + 3 into buffer (k + 3) % 4; wait all but 2 NP.  Returns, per barrier k, the units of this loader's pieces that have landed when the
+    barrier opens, and the unit whose buffer the iteration then overwrites."""
+    np_ = 3 * (3 if lw < 2 else 2)
+    issued, done = [], 0
+
+    def wait_all_but(n):
+        nonlocal done
+        done = max(done, len(issued) - n)
+
+    for k in (0, 1, 2):
+        issued += [k] * np_
+    landed_at, overwritten_at = [], []
+    for k in range(nunits):
+        if k == 0:
+            wait_all_but(2 * np_)
+        landed_at.append(list(issued[:done]))
+        overwritten_at.append(k + 3 - 4)                    # the unit that lived in buffer (k + 3) % 4 before unit k + 3
+        issued += [k + 3] * np_
+        wait_all_but(2 * np_)
+    return landed_at, overwritten_at
+
+
+@pytest.mark.parametrize("lw", range(NLOAD))
+def test_conv1_stream_loader_schedule(lw):
+    """Barrier k lets the compute waves read unit k (buffer k % 4): every piece of it has landed; and the unit an iteration overwrites is one
+    the compute waves finished before that barrier (unit k - 1), never the one they are about to read or a later one."""
+    landed_at, overwritten_at = _conv1_loader_replay(lw, 40)
+    for k, (landed, over) in enumerate(zip(landed_at, overwritten_at)):
+        assert landed.count(k) == 3 * (3 if lw < 2 else 2), (lw, k)     # every piece of unit k has landed when barrier k opens
+        assert over == k - 1, (lw, k, over)                 # its buffer is free: the compute waves passed barrier k only after finishing unit k - 1
+        assert (k + 3) % 4 == (k - 1) % 4
