@@ -118,6 +118,7 @@ template <int EXT, int NB0, int NB1, int MODE, int LW> struct LoaderPlan {
     }
 };
 
+constexpr bool kDirectStores = true;   // growth convs (32 couts) store their rows straight from the accumulators (lane-pair swap: 16 contiguous bytes per lane)
 constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + loader waves (LDS-DMA issue only), one loader per SIMD
 
 // EXT: external 32-channel chunks both convs read; NB0 / NB1: 16-cout blocks of layer 0 / layer 1.
@@ -543,16 +544,28 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
 #pragma unroll
             for (int cg = 0; cg < 3; ++cg) {
                 f32x4 v[NB0];
+                bf16x4 ob[NB0];
 #pragma unroll
                 for (int n = 0; n < NB0; ++n) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[n][e] = real ? fmaxf(a0[n][cg][e], 0.f) : 0.f;
                     const bf16x4 o = {(bf16_t)v[n][0], (bf16_t)v[n][1], (bf16_t)v[n][2], (bf16_t)v[n][3]};
+                    ob[n] = o;
                     const int slice = n * 2 + (q >> 1);
                     *reinterpret_cast<bf16x4*>(wrow + cg * 1024 + 64 * px + 16 * (slice ^ (2 * ((px >> 2) & 1))) + (q & 1) * 8) = o;
                 }
+                if constexpr (MODE == 0 && NB0 == 2 && kDirectStores) {
+                    // 32 couts: lanes q, q ^ 1 trade halves and every lane stores 16 contiguous bytes, a column group one contiguous KiB -- no read-back of the ring row
+                    if (grow) {
+                        const u32x2 au = __builtin_bit_cast(u32x2, ob[0]), cu = __builtin_bit_cast(u32x2, ob[NB0 - 1]);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
+                        const u32x4 ov = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+                        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(grow + cg * 1024 + 64 * px + 2 * ((q & 1) * 16 + 4 * (q & ~1))));
+                    }
+                }
             }
-            if (MODE == 0 && grow) {
+            if (MODE == 0 && grow && !(NB0 == 2 && kDirectStores)) {
                 // the ring row just written IS the row's memory image (64 B per pixel, slices swizzled by 2 * bit2(pixel)): read it back in
                 // lane order and store whole lines
                 static_assert(MODE == 1 || NB0 == 2, "growth convs have 32 output channels");
@@ -623,6 +636,20 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 const float alpha = p.alpha;
                 int t_a, t_line;
                 transpose_offsets(t_a, t_line);
+                if constexpr (MODE == 0 && NB1 == 2 && kDirectStores) {
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) {
+                        bf16x4 ob[2];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            ob[n] = bf16x4{(bf16_t)fmaxf(a1[n][cg][0], 0.f), (bf16_t)fmaxf(a1[n][cg][1], 0.f), (bf16_t)fmaxf(a1[n][cg][2], 0.f), (bf16_t)fmaxf(a1[n][cg][3], 0.f)};
+                        const u32x2 au = __builtin_bit_cast(u32x2, ob[0]), cu = __builtin_bit_cast(u32x2, ob[1]);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(au[0], cu[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(au[1], cu[1], false, false);
+                        const u32x4 ov = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+                        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(grow + cg * 1024 + 64 * px + 2 * ((q & 1) * 16 + 4 * (q & ~1))));
+                    }
+                } else
 #pragma unroll
                 for (int cg = 0; cg < 3; ++cg)
 #pragma unroll
