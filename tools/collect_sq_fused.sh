@@ -10,7 +10,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUS
 {
   echo "# rocprofv3 --kernel-trace --pmc, two passes (SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY | SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES"
   echo "# SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE) over tools/probe_trunk.py 7056 1 (ESRGAN x4 trunk NB=2, bf16, 7056 patches 48x48); last dispatch of each kernel"
-  for k in "chain2_kernel<5, 2, 4, 1, false" "chain2_kernel<5, 2, 4, 1, true" "chain2_kernel<3, 2, 2, 0" "conv3_rows_kernel<2, 4"; do
+  for k in "chain2_kernel<5, 2, 4, 1, false" "chain2_kernel<5, 2, 4, 1, true" "chain2_kernel<3, 2, 2, 0" "conv1_stream_kernel"; do
     echo "## $k"
     python3 tools/pmc_kernel.py "$k" "$OUT/p1" "$OUT/p2"
   done
