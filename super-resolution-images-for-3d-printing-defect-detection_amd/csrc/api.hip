@@ -864,6 +864,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     const int T = m->T;
     int proj_done = -1;                                                       // index of a 1x1 projection op the previous conv's epilogue has already computed
+    int pool_done = -1;                                                       // index of a max-pool op the previous conv's epilogue has already computed
     for (size_t oi = 0; oi < m->ops.size(); ++oi) {
         const Op& op = m->ops[oi];
         int h = H, w = W;
@@ -936,6 +937,16 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 }
                 if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff, m->bufs[op.skip1.buf].blk}; ep.beta1 = op.beta1; }
                 if (op.skip2.buf >= 0) { ep.skip2 = {m->bufp[op.skip2.buf], m->bufs[op.skip2.buf].Cbuf, op.skip2.coff, m->bufs[op.skip2.buf].blk}; ep.beta2 = op.beta2; }
+                if ((ctx->chain_mask & 64) && T == SR_DTYPE_BF16 && oi + 1 < m->ops.size() && m->ops[oi + 1].kind == OP_POOL && m->ops[oi + 1].in.buf == op.out.buf &&
+                    op.out.buf >= 0 && m->ops[oi + 1].out.buf >= 0 && cs.w.rows && cs.w.NT == 4 && cs.w.CoutP == cs.w.Cout && op.skip1.buf < 0 && op.skip2.buf < 0 &&
+                    op.d2s == 1 && !op.clip && op.act != SR_ACT_TANH && m->taps.count((int)oi) == 0 && cB == B && !m->grid_now[op.out.buf].gx && h >= 2 && w >= 2 &&
+                    m->bufs[m->ops[oi + 1].out.buf].Cbuf % 8 == 0 && m->bufs[m->ops[oi + 1].out.buf].Cbuf >= cs.w.Cout) {
+                    // conv -> MaxPooling2D (every VGG16 block ends so): the pool rides in the conv's epilogue, the full-resolution tensor is never stored
+                    const Op& opl = m->ops[oi + 1];
+                    ep.pool_out = TensorView{m->bufp[opl.out.buf], m->bufs[opl.out.buf].Cbuf, opl.out.coff, m->bufs[opl.out.buf].blk};
+                    ep.pool_grid = m->grid_now[opl.out.buf];
+                    pool_done = (int)oi + 1;
+                }
                 if (op.proj >= 0 && (ctx->chain_mask & 8) && cs.w.rows && cs.w.NT == 4 && cs.w.Cout / (op.d2s * op.d2s) == 64 && cs.w.CoutP == cs.w.Cout &&
                     op.out.buf >= 0 && !m->bufs[op.out.buf].blk && op.skip2.buf < 0 && !op.clip && op.act != SR_ACT_TANH && m->bufs[op.out.buf].Cbuf % 4 == 0) {
                     // the SelfAttention layer that follows opens with three 1x1 convs of this conv's output: computed here, from registers
@@ -968,6 +979,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                                             m->bufs[op.out.buf].Cbuf, op.out.coff, st);
                 break;
             case OP_POOL:
+                if ((int)oi == pool_done) break;                              // computed by the conv in front of it
                 rc = maxpool2_launch(ctx, T, m->bufp[op.in.buf], B, h, w, m->bufs[op.in.buf].C, m->bufs[op.in.buf].Cbuf, m->bufp[op.out.buf],
                                      m->bufs[op.out.buf].Cbuf, st, m->grid_now[op.in.buf], m->grid_now[op.out.buf]);
                 break;

@@ -626,6 +626,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.f2w = nullptr; p.f2part = nullptr; p.f2c = 0;
     p.pjw = nullptr; p.pjbias = nullptr; p.pjout = nullptr; p.pj_cs = 0; p.pj_coff = 0; p.pj_rs = 0; p.pj_nblk = 0;
     p.cell_h = ep.cell_h; p.cell_w = ep.cell_w;
+    p.plout = nullptr; p.pl_cs = 0; p.pl_coff = 0; p.pl_gx = p.pl_ch = p.pl_cw = p.pl_Wv = 0;
     const int osz = p.out_f32 ? 4 : esz;
     bool vec = (y_cs % 4 == 0) && (y_coff % 4 == 0) && ((uintptr_t)y % (4 * osz) == 0) && (p.Cd % 4 == 0);
     if (p.s1) vec = vec && (p.s1_cs % 4 == 0) && (p.s1_coff % 4 == 0) && ((uintptr_t)p.s1 % (4 * esz) == 0);
@@ -642,6 +643,13 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     }
     if ((ep.cell_h || ep.cell_w) && !(w.rows && vec && w.Cout % 4 == 0 && ep.act != SR_ACT_TANH && r == 1 && !ep.pj && !ep.f2 && ep.cell_h >= 2 && ep.cell_w >= 2))
         return ctx->fail(SR_ERR_INVALID, "conv: separator masks need the bf16 3x3 kernel's vector epilogue");
+    if (ep.pool_out.p) {
+        if (!(w.rows && w.NT == 4 && w.CoutP == w.Cout && r == 1 && !p.s1 && !p.s2 && !ep.clip01 && ep.act != SR_ACT_TANH && !ep.pj && !ep.f2 && !ep.cell_h && !ep.cell_w && !ep.pool_out.blk &&
+              ep.pool_out.cs % 8 == 0 && ep.pool_out.coff % 8 == 0 && ((uintptr_t)ep.pool_out.p % 16) == 0 && ep.pool_out.cs - ep.pool_out.coff >= w.Cout && H >= 2 && W >= 2))
+            return ctx->fail(SR_ERR_INVALID, "conv: the fused max-pool follows a bf16 3x3 conv in 64-cout tiles without skips");
+        p.plout = static_cast<char*>(const_cast<void*>(ep.pool_out.p)); p.pl_cs = ep.pool_out.cs; p.pl_coff = ep.pool_out.coff;
+        p.pl_gx = ep.pool_grid.gx; p.pl_ch = ep.pool_grid.ch; p.pl_cw = ep.pool_grid.cw; p.pl_Wv = ep.pool_grid.Wv;
+    }
     if (ep.pj) {
         // every output pixel's 64 channels come from one workgroup: a 64-cout conv, or depth_to_space of 64-channel sub-pixels
         if (!(w.rows && w.NT == 4 && p.Cd == 64 && w.CoutP == w.Cout && !yv.blk && !p.s2 && !ep.clip01 && ep.act != SR_ACT_TANH && vec && !ep.f2 && ep.pj->a &&
@@ -663,6 +671,9 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         const double px = (double)B * H * W;
         rec = ctx->prof_open("conv_rows_rgbtail<bf16,64->64->rgb>", 2.0 * px * 9 * w.Cin * (w.Cout + ep.f2->c2),
                              px * w.Cin * esz + (double)rgbtail_partial_bytes(B, H, W), st);
+    } else if (ctx->prof && ep.pool_out.p) {
+        const double px = (double)B * H * W;
+        rec = ctx->prof_open("conv_rows_pool<bf16,k3,nt4+maxpool2>", 2.0 * px * 9.0 * w.Cin * w.Cout, px * ((double)w.Cin * esz + 0.25 * w.Cout * esz), st);
     } else if (ctx->prof && ep.pj) {
         const double px = (double)B * H * W;
         rec = ctx->prof_open("conv_rows_proj<bf16,k3,nt4+1x1>", 2.0 * px * (9.0 * w.Cin * w.Cout + (double)w.Cout * 16 * ep.pj->nblk),

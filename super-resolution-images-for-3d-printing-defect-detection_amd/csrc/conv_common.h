@@ -34,6 +34,9 @@ struct ConvParams {
     const float* pjbias;
     char* pjout; int64_t pj_cs; int pj_coff; int pj_rs; int pj_nblk;
     int cell_h, cell_w; // conv_rows fast epilogue: separator rows / columns of a CellGrid layout are not stored (0 = none)
+    // conv_rows, fused 2x2 max-pool (conv_rows.hip, rows_pool2): the conv's output is not stored; its VALID 2x2 / stride-2 maximum goes to plout
+    // ([B][H/2][W/2] NHWC pixels of pl_cs channels, or packed in a CellGrid: pl_gx images per row of cells of pl_ch x pl_cw pixels, pl_Wv pixels per row)
+    char* plout; int64_t pl_cs; int pl_coff; int pl_gx, pl_ch, pl_cw, pl_Wv;
 };
 
 __device__ __forceinline__ int choff(int c, int ps) { return (c >> 5) * ps + (c & 31); }

@@ -206,7 +206,47 @@ __device__ __forceinline__ void rows_epilogue_proj(const ConvParams& p, f32x4 (&
     }
 }
 
-template <int NB16, int R, bool STAMP, bool FUSE2 = false>
+// Fused 2x2 max-pool (FUSE2 == 2; 64 couts per workgroup).  Every VGG16 block ends conv -> MaxPooling2D (VGG16_model.py:69-73): as two kernels the conv's
+// full-resolution output is written and read back for a reduction that keeps a quarter of it.  The tile's rows pair up across waves (three rows per
+// wave), so the bf16 outputs go through the tile's LDS (12 x 16 pixels x 128 B = 24 KiB): thread v < 384 takes the maximum of the four pixels of pooled
+// position v / 8 for channel octet v % 8 and stores 16 bytes.  max of bf16 values is exact: the pooled tensor is the two-kernel path's bit for bit.
+template <int R>
+__device__ __forceinline__ void rows_pool2(const ConvParams& p, f32x4 (&acc)[R][4], const f32x4 (&biasv)[4], char* smem, int b, int y0, int x0, int ct, int wave,
+                                           int px, int q, int tid) {
+    constexpr int TH = 4 * R, PB = 128 + 16;                       // bytes per pixel in LDS (64 channels + 16: the 8-byte writes of a lane group spread over the banks)
+    const float slope = p.act == SR_ACT_RELU ? 0.f : (p.act == SR_ACT_LRELU ? 0.2f : 1.f);
+    const float alpha = p.alpha;
+    __syncthreads();                                               // every wave is done with the input image and the weights
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x4 v = acc[r][n] + biasv[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope) * alpha;
+            *reinterpret_cast<bf16x4*>(smem + ((wave * R + r) * 16 + px) * PB + (16 * n + 4 * q) * 2) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+    __syncthreads();
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int v = tid + 256 * it;
+        if (v >= (TH / 2) * 8 * 8) break;
+        const int cv = v & 7, ppx = (v >> 3) & 7, pr = v >> 6;
+        const int oy = (y0 >> 1) + pr, ox = (x0 >> 1) + ppx;
+        if (oy >= Ho || ox >= Wo) continue;
+        const char* s = smem + ((2 * pr) * 16 + 2 * ppx) * PB + cv * 16;
+        const bf16x8 v00 = *reinterpret_cast<const bf16x8*>(s), v01 = *reinterpret_cast<const bf16x8*>(s + PB);
+        const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(s + 16 * PB), v11 = *reinterpret_cast<const bf16x8*>(s + 17 * PB);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf(fmaxf((float)v00[e], (float)v01[e]), fmaxf((float)v10[e], (float)v11[e]));
+        const int64_t pix = p.pl_gx == 0 ? ((int64_t)b * Ho + oy) * Wo + ox : ((int64_t)(b / p.pl_gx) * p.pl_ch + oy) * p.pl_Wv + (b % p.pl_gx) * p.pl_cw + ox;
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.plout) + pix * p.pl_cs + p.pl_coff + ct * 64 + cv * 8) = o;
+    }
+}
+
+template <int NB16, int R, bool STAMP, int FUSE2 = 0>
 __global__ void __launch_bounds__(256, NB16 == 4 ? (R > 3 ? 2 : 3) : 4) conv3_rows_kernel(ConvParams p) {
     constexpr int TH = 4 * R, TW = 16, PH = TH + 2, PW = TW + 2;
     constexpr int NPIX = PH * PW;
@@ -420,8 +460,14 @@ __global__ void __launch_bounds__(256, NB16 == 4 ? (R > 3 ? 2 : 3) : 4) conv3_ro
     f32x4 biasv[NB16];
 #pragma unroll
     for (int n = 0; n < NB16; ++n) biasv[n] = *reinterpret_cast<const f32x4*>(lbias + n * 16 + 4 * q);
-    if constexpr (FUSE2) {
-        static_assert(!FUSE2 || NB16 == 4, "the fused RGB tail needs all 64 channels of a pixel in one workgroup");
+    if constexpr (FUSE2 == 2) {
+        static_assert(FUSE2 != 2 || NB16 == 4, "the fused max-pool is built for 64-cout workgroups");
+        rows_pool2<R>(p, acc, biasv, smem, b, y0, x0, ct, wave, px, q, tid);
+        STAMP_AT(15);
+        return;
+    }
+    if constexpr (FUSE2 == 1) {
+        static_assert(FUSE2 != 1 || NB16 == 4, "the fused RGB tail needs all 64 channels of a pixel in one workgroup");
         rows_fuse2<R>(p, acc, biasv, smem, ((int64_t)b * p.tilesY + ty) * tilesX + tx, y0, x0, wave, lane, px, q, tid);
         STAMP_AT(15);
         return;
@@ -460,7 +506,7 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     if (nwg >= (1ll << 31)) return ctx->fail(SR_ERR_INVALID, "conv_rows: too many workgroups for one launch");
     p.tilesX = (nct << 16) | tilesX;
     dim3 grid((unsigned)nwg, 1u);
-    if (p.dbg && !p.f2w) {   // diagnostic stamped variant: 16 stamps per workgroup, refused when the buffer is too small for this grid
+    if (p.dbg && !p.f2w && !p.plout) {   // diagnostic stamped variant: 16 stamps per workgroup, refused when the buffer is too small for this grid
         if (nwg * 16 * (int64_t)sizeof(unsigned long long) > ctx->stamp_cap)
             return ctx->fail(SR_ERR_INVALID, "conv_rows: the stamp buffer is too small for this launch (sr_debug_stamp_bytes_needed(0, workgroups))");
         auto kd = conv3_rows_kernel<NB16, R, true>;
@@ -472,7 +518,7 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     if constexpr (NB16 == 4 && R == 3) {                     // (the finishing pass assumes 12 x 16 tiles)
         if (p.f2w) {
             if (nct != 1) return ctx->fail(SR_ERR_INVALID, "conv_rows: the fused RGB tail needs a 64-cout conv");
-            auto kf = conv3_rows_kernel<NB16, R, false, true>;
+            auto kf = conv3_rows_kernel<NB16, R, false, 1>;
             if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kf), lds)) return rc;
             hipLaunchKernelGGL(kf, grid, dim3(256), lds, st, p);
             SR_HIP(ctx, hipGetLastError());
@@ -480,6 +526,17 @@ int launch_rows(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
         }
     }
     if (p.f2w) return ctx->fail(SR_ERR_INVALID, "conv_rows: the fused RGB tail needs a 64-cout conv");
+    if constexpr (NB16 == 4 && R == 3) {
+        if (p.plout) {
+            static_assert(NB16 != 4 || 12 * 16 * 144 <= lds, "rows_pool2 parks the tile's outputs in its LDS");
+            auto kp = conv3_rows_kernel<NB16, R, false, 2>;
+            if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kp), lds)) return rc;
+            hipLaunchKernelGGL(kp, grid, dim3(256), lds, st, p);
+            SR_HIP(ctx, hipGetLastError());
+            return SR_OK;
+        }
+    }
+    if (p.plout) return ctx->fail(SR_ERR_INVALID, "conv_rows: the fused max-pool needs 64-cout workgroups");
     auto kern = conv3_rows_kernel<NB16, R, false>;
     if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);

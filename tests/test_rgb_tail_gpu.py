@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def fused_ctx(ctx):
     yield ctx
-    ctx.set_fused(63, 0)
+    ctx.set_fused(127, 0)
 
 
 def kernels_of(ctx, fn):
@@ -195,6 +195,14 @@ def test_vgg16_block5_packed_batches(fused_ctx, patch):
     got = [m.forward(ctx.to_device(x, torch.bfloat16)).clone() for x in xs]
     for a, b in zip(want, got):
         assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    # ... and with every block's MaxPooling2D computed in the epilogue of the conv in front of it (max of bf16 values is exact), alone and together with the packing
+    for mask in (64, 127):
+        ctx.set_fused(mask, 0)
+        (y_p, ks) = kernels_of(ctx, lambda: m.forward(ctx.to_device(xs[0], torch.bfloat16)))
+        assert any(k.startswith("conv_rows_pool") for k in ks), ks
+        assert torch.equal(y_p, want[0]), (mask, float((y_p.float() - want[0].float()).abs().max()))
+        assert torch.equal(m.forward(ctx.to_device(xs[2], torch.bfloat16)), want[2]), mask
+    ctx.set_fused(31, 0)
     y_t, taps = m.forward_with_taps(ctx.to_device(xs[0], torch.bfloat16), ["block5_conv3"])       # plain layout for this call
     assert torch.equal(y_t, want[0]) and taps["block5_conv3"].shape == (5, patch // 16, patch // 16, 512)
     assert torch.equal(m.forward(ctx.to_device(xs[2], torch.bfloat16)), want[2])                  # packed again
