@@ -1,8 +1,12 @@
-"""The generator's last two convs as one kernel (csrc/conv_rows.hip, rows_fuse2 + rgbtail_finish_kernel): final_conv2 (64 -> image
-channels, tanh; ESRGAN_model.py:341) is computed inside final_conv1's epilogue as a 1x1 conv to 9 x C "tap channels" followed by a shifted
-sum over each tile's halo'd region, so final_conv1's 64-channel output is never stored.  Checked against the two-kernel path
-(sr_debug_set_fused without bit 2) and against the CPU oracle: tile-exact, ragged and multi-tile images, one and three image channels,
-fp32 and bf16 caller tensors, and an exact-integer case in which both device paths and the oracle must agree to the last bit."""
+"""Work computed in the epilogue of the kernel that holds its operands (csrc/conv_rows.hip), each against the path that runs the layers as separate
+kernels (sr_debug_set_fused without the bit) and against the CPU oracle:
+  * the generator's last two convs as one kernel (rows_fuse2 + rgbtail_finish_kernel): final_conv2 (64 -> image channels, tanh; ESRGAN_model.py:341)
+    as a 1x1 conv to 9 x C "tap channels" inside final_conv1's epilogue followed by a shifted sum over each tile's halo'd region -- tile-exact, ragged
+    and multi-tile images, one and three image channels, fp32 and bf16 caller tensors, and an exact-integer case in which both device paths and the
+    oracle must agree to the last bit;
+  * SelfAttention's f / g / h projections inside the conv that produces the layer's input (rows_epilogue_proj);
+  * the VGG16 classifier's block 5 on batches packed into one tall image (CellGrid) and every block's MaxPooling2D inside the conv in front of it
+    (rows_pool2): bit for bit the plain path."""
 import numpy as np
 import pytest
 import torch
