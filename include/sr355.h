@@ -104,7 +104,8 @@ int64_t sr_debug_stamp_bytes_needed(int which, int64_t workgroups);
  * images (the VGG16 classifier's block 5: 6 x 6 pixels for 96-pixel patches) packed side by side with zero separator rows / columns into one
  * tall image for the 3x3 kernel, whose 12 x 16 output tiles a single such image would fill to 19 %; bit 5 = conv1 of a dense block (64 -> 32 channels, the block's one
  * HBM-bound conv) on a streaming line-buffer kernel with its weights resident in LDS; bit 6 = a MaxPooling2D computed in the epilogue of the conv in front of it
- * (every VGG16 block ends conv -> pool: the full-resolution tensor is never stored); default 127.
+ * (every VGG16 block ends conv -> pool: the full-resolution tensor is never stored); bit 7 = 3x3 convs from 64 input channels (the generator's
+ * up-sampling convs, EDSR's body) on a persistent kernel that keeps a 64-cout tile's weights in LDS; default 255.
  * mask 0 = layer by layer (the A/B switch of the parity tests and of tools/ benchmarks).  max_workgroups > 0 caps the persistent grid (tests: several images per workgroup
  * at small batches); 0 = one workgroup per CU. */
 int  sr_debug_set_fused(sr_ctx* ctx, int mask, int max_workgroups);

@@ -55,7 +55,7 @@ struct sr_ctx {
     void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
     int num_cus = 0;
     int cu_count();               // compute units of the device (queried once)
-    int chain_mask = 127;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid, bit 5: conv1 of a dense block on the streaming kernel, bit 6: a 2x2 max-pool inside the conv in front of it (sr_debug_set_fused; default all)
+    int chain_mask = 255;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid, bit 5: conv1 of a dense block on the streaming kernel, bit 6: a 2x2 max-pool inside the conv in front of it, bit 7: 64-input-channel 3x3 convs on the persistent kernel of conv_stream.hip (sr_debug_set_fused; default all)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
 

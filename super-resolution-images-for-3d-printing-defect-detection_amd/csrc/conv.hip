@@ -666,6 +666,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         p.f2w = static_cast<const char*>(ep.f2->a); p.f2part = ep.f2_part; p.f2c = ep.f2->c2;
     }
     const int nct = w.CoutP / 32 / w.NT;
+    const bool stream = (ctx->chain_mask & 128) != 0 && conv_stream_supported(w, p);
     int rec = -1;
     if (ctx->prof && ep.f2) {
         const double px = (double)B * H * W;
@@ -680,7 +681,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
                              px * ((double)w.Cin * esz + (double)w.Cout * osz + (p.s1 ? (double)w.Cout * esz : 0.0) + (double)r * r * 16 * ep.pj->nblk * esz), st);
     } else if (ctx->prof) {
         char nm[96];
-        snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.few ? "few" : w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),
+        snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.few ? "few" : stream ? "stream" : w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),
                  w.dtype == SR_DTYPE_BF16 ? "bf16" : "f32", w.KS, w.KGPT, w.NT);
         const double px = (double)B * H * W;
         double bytes = px * ((double)w.Cin * esz + (double)w.Cout * osz);
@@ -689,7 +690,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         rec = ctx->prof_open(nm, 2.0 * px * w.KS * w.KS * w.Cin * w.Cout, bytes, st);
     }
     const int rc = w.few ? (w.KS == 3 ? launch_fewcout<3>(ctx, p, st) : launch_fewcout<5>(ctx, p, st))
-                   : w.rows ? conv_rows_launch(ctx, w, p, st) : w.pw ? conv_pw_launch(ctx, w, p, st)
+                   : stream ? conv_stream_launch(ctx, w, p, st) : w.rows ? conv_rows_launch(ctx, w, p, st) : w.pw ? conv_pw_launch(ctx, w, p, st)
                           : ((w.dtype == SR_DTYPE_BF16) ? dispatch<bf16_t>(ctx, w, p, nct, st) : dispatch<float>(ctx, w, p, nct, st));
     ctx->prof_close(rec, st);
     return rc;

@@ -124,5 +124,8 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int oy, in
 
 // bf16 3x3 "row-sliding" kernel (conv_rows.hip)
 int conv_rows_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams& p, hipStream_t st);
+// bf16 3x3 from 64 input channels, 64 couts per workgroup, as a persistent kernel with resident weights (conv_stream.hip)
+bool conv_stream_supported(const ConvWeights& w, const convk::ConvParams& p);
+int conv_stream_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams& p, hipStream_t st);
 // bf16 1x1 streaming kernel (conv_pw.hip)
 int conv_pw_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams& p, hipStream_t st);

@@ -42,6 +42,12 @@ def test_fused_dense_kernels_use_no_scratch():
                         "--scratch-only"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "1 kernels checked" in r.stdout and " 0 problems" in r.stdout
+    # the persistent 64-input-channel kernel of conv_stream.hip (counted waits in its loaders as well)
+    src2 = os.path.join(ROOT, "super-resolution-images-for-3d-printing-defect-detection_amd", "csrc", "conv_stream.hip")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch_hazards.py"), "--source", src2, "--match", "conv64_stream_kernel",
+                        "--scratch-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "1 kernels checked" in r.stdout and " 0 problems" in r.stdout
 
 
 def test_checker_flags_a_register_touched_under_an_outstanding_load():

@@ -62,11 +62,11 @@ def device_trace(ctx, dtype, w, x, nb=NB, stages=STAGES):
         # epilogue: another order of the fp32 additions), so the two bf16 images may differ by a flipped rounding here and there ...
         d = (y.float() - y2.float()).abs()
         assert float(d.max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 0.01, (float(d.max()), float((d > 0).float().mean()))
-        ctx.set_fused(127 & ~4, 0)                 # ... and are the same image when that pair runs as two kernels in both
+        ctx.set_fused(255 & ~4, 0)                 # ... and are the same image when that pair runs as two kernels in both
         try:
             assert torch.equal(y, m.forward(ctx.to_device(x, td)))
         finally:
-            ctx.set_fused(127, 0)
+            ctx.set_fused(255, 0)
     return y.float().cpu().numpy(), {name: taps[dev].cpu().numpy() for name, dev in stages}
 
 
