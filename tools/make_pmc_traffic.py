@@ -8,7 +8,7 @@ import csv, glob, json, sys
 NAMES = {"conv3_rows_kernel<4,3,false,true>": "conv_rows_rgbtail<bf16,64->64->rgb>",      # first match wins: the fused RGB tail before the plain 64-cout kernel
          "conv3_rows_kernel<1,": "conv_rows<bf16,k3,kg1,nt1>", "conv3_rows_kernel<2,": "conv_rows<bf16,k3,kg1,nt2>",
          "conv3_rows_kernel<4,": "conv_rows<bf16,k3,kg1,nt4>",
-         "conv1_stream_kernel": "dense_conv1_stream<bf16,64->32>",
+         "conv1_stream_kernel": "dense_conv1_stream<bf16,64->32>", "conv64_stream_kernel": "conv_stream<bf16,k3,kg1,nt4>",
          "chain2_kernel<5,2,4,1,": "dense_tail_fused<bf16,conv4+conv5>", "chain2_kernel<3,2,2,0,": "dense_pair_fused<bf16>"}
 
 
