@@ -132,6 +132,14 @@ class ESRGAN(DeviceModelMixin):
         if getattr(self, "_trainer", None) is not None:
             self._trainer.allreduce, self._trainer.allreduce_flat = self.grad_allreduce, self.grad_allreduce_flat
 
+    def set_weights(self, weights, trained=True):
+        """As every wrapper's; a live trainer follows: its device-resident parameter bucket takes the new values and Adam starts over
+        (round 3 left the trainer on the old parameters without an error)."""
+        super().set_weights(weights, trained)
+        tr = getattr(self, "_trainer", None)
+        if tr is not None and weights is not tr._gw:
+            tr.load_generator_weights(self.weights)
+
     def _sync_from_trainer(self):
         tr = self._trainer
         self.set_weights(tr.gw)

@@ -296,12 +296,15 @@ class ESRGANTrainer:
             self._gdev[id(a)] = (a, self._gflat[o:o + a.size].view(tuple(a.shape)))
             o += a.size
         self._g_host_stale = False
-        self.dw = {n: (np.asarray(k, np.float32), np.asarray(b, np.float32)) for n, (k, b) in d_weights.items()}
+        # d_weights / vgg_weights None: a generator-only trainer (pixel_step: sr355.recipes' L1 fit); train_step then refuses
+        self.dw = None if d_weights is None else {n: (np.asarray(k, np.float32), np.asarray(b, np.float32)) for n, (k, b) in d_weights.items()}
         self.vw = vgg_weights
         rng = np.random.default_rng(u_seed)               # tfa initialises u ~ TruncatedNormal(stddev 0.02), shape [1, Cout]
-        self.u = {n: np.clip(rng.normal(0, 0.02, (1, self.dw[n][0].shape[-1])), -0.04, 0.04).astype(np.float32) for n in DISC_LAYERS}
+        self.u = None if self.dw is None else {n: np.clip(rng.normal(0, 0.02, (1, self.dw[n][0].shape[-1])), -0.04, 0.04).astype(np.float32)
+                                               for n in DISC_LAYERS}
         self.g_lr0, self.d_lr0 = g_lr, d_lr
-        self.g_opt, self.d_opt = DeviceAdam(ctx, self._gflat, g_lr, epsilon=1e-7), Adam(self.dw, d_lr, epsilon=1e-7)
+        self.g_opt = DeviceAdam(ctx, self._gflat, g_lr, epsilon=1e-7)
+        self.d_opt = None if self.dw is None else Adam(self.dw, d_lr, epsilon=1e-7)
         self.step = 0
         # data parallel: `allreduce` = callable(dict of host grads) -> averaged dict (the discriminator's, whose spectral normalisation lives on
         # the host); `allreduce_flat` = callable(flat device tensor) -> averaged tensor for the generator's bucket (RCCL reduces it where it
@@ -320,6 +323,30 @@ class ESRGANTrainer:
                     o += a.size
             self._g_host_stale = False
         return self._gw
+
+    @gw.setter
+    def gw(self, weights):
+        self.load_generator_weights(weights)
+
+    def load_generator_weights(self, weights, reset_optimizer=True):
+        """Replace the generator's parameters (ESRGAN.set_weights / load after the trainer exists): copies into the device bucket in
+        parameter order; by default Adam's moments and step count start over, as a freshly compiled Keras model's would."""
+        if set(weights) != set(self._gw):
+            raise ValueError("generator weights: layer names differ from the trainer's graph")
+        parts = []
+        for n, pair in self._gw.items():
+            for a, new in zip(pair, weights[n]):
+                new = np.asarray(new, np.float32)
+                if new.shape != a.shape:
+                    raise ValueError(f"{n}: shape {new.shape} != {a.shape}")
+                np.copyto(a, new)
+                parts.append(a.ravel())
+        self._gflat.copy_(self.ctx.to_device(np.concatenate(parts)))
+        self._g_host_stale = False
+        if reset_optimizer:
+            self.g_opt.m.zero_()
+            self.g_opt.v.zero_()
+            self.g_opt.t = 0
 
     def _bucket_to_dict(self, flat):
         """flat host array in parameter order -> {layer: (dk, db)} views"""
@@ -385,9 +412,30 @@ class ESRGANTrainer:
             cache[id(a)] = (a, flat[o:o + a.size].view(tuple(a.shape)))
             o += a.size
 
+    def pixel_step(self, lr_images, hr_images):
+        """One generator update on the pixel loss alone (mean |hr - G(lr)|, ESRGAN_model.py:433-445; the generator half of _train_step,
+        :506-531, without the adversarial / perceptual / spectral terms): sr355.recipes' fit.  -> the L1 value before the update."""
+        ctx = self.ctx
+        lr_t, hr_t = ctx.to_device(np.asarray(lr_images, np.float32)), ctx.to_device(np.asarray(hr_images, np.float32))
+        tg = Tape(ctx, self._gw, devcache=dict(self._gdev))
+        y = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att)
+        pix = float(ctx.l1(hr_t, y.v).item())
+        y.g = ctx.eltwise(L.ELT_SIGN_DIFF, y.v, hr_t, 1.0 / y.v.numel(), 0.0)
+        tg.backward()
+        g_flat = self._gather_grads(tg.grads)
+        if self.allreduce_flat is not None:
+            g_flat = self.allreduce_flat(g_flat)
+        self.g_opt.lr = staircase_lr(self.g_lr0, self.step)
+        self.g_opt.apply(self._gflat, g_flat)
+        self._g_host_stale = True
+        self.step += 1
+        return pix
+
     def train_step(self, lr_images, hr_images):
         """-> {'g_loss', 'd_loss', parts...}; weights, u, optimiser states advance in place (ESRGAN_model.py:475-533)."""
         ctx = self.ctx
+        if self.dw is None or self.vw is None:
+            raise RuntimeError("ESRGANTrainer was built without discriminator / VGG19 weights: only pixel_step is available")
         lr_t, hr_t = ctx.to_device(np.asarray(lr_images, np.float32)), ctx.to_device(np.asarray(hr_images, np.float32))
         devc = {}                                          # device copies of this step's parameter arrays (one upload per array)
         if not hasattr(self, "_vggc"):
