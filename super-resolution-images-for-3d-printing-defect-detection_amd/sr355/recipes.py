@@ -50,16 +50,15 @@ def near_identity_generator(layer_shapes, seed=7000, eps_out=0.02, g_conv5=0.3, 
             first = n == "upsample_0_conv"
             k *= eps_out
             b *= eps_out
-            g = (_G1 / _G0) if first else (_G2 / (1.2 * _G1))            # a pair behind a LeakyReLU carries 1.2 x its value
+            # the +/- pair in front: (v, -v) behind initial_conv / the trunk, (lrelu(v), lrelu(-v)) behind a LeakyReLU: difference 2 v resp. 1.2 v
+            g = (_G1 / (2.0 * _G0)) if first else (_G2 / (1.2 * _G1))
             for i in (0, 1):
                 for j in (0, 1):
                     taps, o = g * np.outer(_BILINEAR[i], _BILINEAR[j]), (i * 2 + j) * 64
                     for c in range(3):
                         k[..., o + c], k[..., o + 3 + c], b[o + c], b[o + 3 + c] = 0.0, 0.0, 0.0, 0.0
-                        k[:, :, c, o + c], k[:, :, c, o + 3 + c] = 0.5 * taps, -0.5 * taps
-                        k[:, :, 3 + c, o + c], k[:, :, 3 + c, o + 3 + c] = -0.5 * taps, 0.5 * taps
-                        if first:                                         # in front of the first LeakyReLU the pair is (a, -a): same 1.0 in total
-                            pass
+                        k[:, :, c, o + c], k[:, :, c, o + 3 + c] = taps, -taps
+                        k[:, :, 3 + c, o + c], k[:, :, 3 + c, o + 3 + c] = -taps, taps
         elif n == "final_conv1":
             k *= eps_out
             b *= eps_out
