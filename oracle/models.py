@@ -250,7 +250,7 @@ def _sa(x, w, name, dtype, parts=None, bf16_storage=False):
 
 
 def esrgan_g_forward(x, w, scale=2, num_rrdb=23, dtype=np.float32, attention=True, parts=None, bf16_storage=False,
-                     bf16_output=True):
+                     bf16_output=True, fused_tail=True):
     """ESRGAN_model.py:303-345.  x in [-1,1]; output tanh in [-1,1].
 
     bf16_storage=True is the same graph with every tensor the bf16 device path keeps in HBM rounded to bf16 where the
@@ -258,7 +258,9 @@ def esrgan_g_forward(x, w, scale=2, num_rrdb=23, dtype=np.float32, attention=Tru
     rrdb_in + 0.2*(x + 0.2*conv5) once for the third dense block of an RRDB, whose own output is never stored -- plus the
     attention roundings of ops.self_attention_bf16_storage.  Arithmetic inside a layer stays in `dtype`.  It is the
     like-for-like reference for BASELINE configs[2] (bf16): what is left between it and the device is accumulation
-    order.  `parts`, when a dict, also receives the stage outputs 'initial_conv', 'rrdb_<b>', 'trunk_add',
+    order.  fused_tail (bf16_storage only): final_conv1's activation is not a stored tensor on the device's default path -- final_conv2 is
+    computed in final_conv1's epilogue from a bf16 hi + lo pair of it (ops.round_bf16_hilo); False = the layer-by-layer path, which
+    stores it as one bf16 value.  `parts`, when a dict, also receives the stage outputs 'initial_conv', 'rrdb_<b>', 'trunk_add',
     'upsample_<i>', 'final_conv1' (the trace the parity tests compare stage by stage)."""
     q = ops.round_bf16 if bf16_storage else _id
     if bf16_storage:
@@ -292,11 +294,13 @@ def esrgan_g_forward(x, w, scale=2, num_rrdb=23, dtype=np.float32, attention=Tru
             x = _sa(x, w, "self_attention_upsample_0", dtype, parts, bf16_storage)
             if parts is not None:
                 parts["self_attention_upsample_0"] = x
-    x = q(ops.conv2d(x, *w["final_conv1"], act="relu", dtype=dtype))
+    x = ops.conv2d(x, *w["final_conv1"], act="relu", dtype=dtype)
+    if bf16_storage:
+        x = ops.round_bf16_hilo(x) if fused_tail else q(x)
     if parts is not None:
         parts["final_conv1"] = x
     y = ops.conv2d(x, *w["final_conv2"], act="tanh", dtype=dtype)
-    return q(y) if bf16_output else y
+    return q(y) if (bf16_storage and bf16_output) else y
 
 
 DISC_STRIDES = [1, 2, 1, 2, 1, 2]

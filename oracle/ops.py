@@ -29,6 +29,14 @@ def round_bf16(x):
     return a.to(torch.bfloat16).to(torch.float32).numpy().astype(out_dtype, copy=False)
 
 
+def round_bf16_hilo(x):
+    """x as the sum of two bf16 values, hi = bf16(x) and lo = bf16(x - hi): how the device's fused RGB tail feeds final_conv1's activation --
+    never stored -- into final_conv2's product (csrc/conv_rows.hip rows_fuse2).  ~16 mantissa bits."""
+    x = np.asarray(x)
+    hi = round_bf16(x)
+    return hi + round_bf16(x - hi)
+
+
 # --------------------------------------------------------------------------------------
 # Activations (Keras semantics; SURVEY.md A.12)
 # --------------------------------------------------------------------------------------

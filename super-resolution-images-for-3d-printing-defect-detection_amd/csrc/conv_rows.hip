@@ -55,8 +55,8 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // K ordering of an MFMA is free as long as the A fragment (host-packed, rgbtail_pack_weights) uses the same one.  So: 4 MFMAs per output row
 // and wave give z (fp32, 32 tap channels); z goes to LDS; thread i < 14 * 18 sums, for position i of the tile's halo'd region, the taps whose
 // source pixel lies inside the tile, and stores 3 floats.  h is never written.  rgbtail_finish_kernel adds the <= 4 tiles' partial sums of
-// an output pixel in a fixed order, then bias, tanh, store.  h is rounded to bf16 before the 1x1 (what the layer-by-layer path stores), the
-// sums are fp32 throughout; only the order of the fp32 additions differs from the separate conv.
+// an output pixel in a fixed order, then bias, tanh, store.  h enters the 1x1 as a bf16 hi + lo pair (round 4; the layer-by-layer path stores and
+// re-reads it as ONE bf16 value), the sums are fp32 throughout.
 template <int R>
 __device__ __forceinline__ void rows_fuse2(const ConvParams& p, f32x4 (&acc)[R][4], const f32x4 (&biasv)[4], char* smem, int64_t tile, int y0, int x0,
                                            int wave, int lane, int px, int q, int tid) {
@@ -73,7 +73,10 @@ __device__ __forceinline__ void rows_fuse2(const ConvParams& p, f32x4 (&acc)[R][
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool live = y0 + wave * R + r < p.H && ox < p.W;             // pixels of a ragged tile beyond the image contribute nothing
-        bf16x8 hb[2];
+        // h enters the 1x1 product as hi + lo, two bf16 values (lo = the part of the fp32 value the first rounding dropped): the activation is
+        // never stored, so nothing asks for its rounding to 8 mantissa bits, and of the output end's storage roundings this one weighed most in
+        // the image (round 4: 1.6 dB of the bf16 path's noise floor against the fp32 graph; 4 more MFMAs per row beside final_conv1's 72)
+        bf16x8 hb[2], lb[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -82,11 +85,15 @@ __device__ __forceinline__ void rows_fuse2(const ConvParams& p, f32x4 (&acc)[R][
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[r][2 * hf + u][e] + biasv[2 * hf + u][e];
                     v = fmaxf(v, v * slope) * alpha;
-                    hb[hf][4 * u + e] = live ? (bf16_t)v : (bf16_t)0.f;
+                    const bf16_t hi = (bf16_t)v;
+                    hb[hf][4 * u + e] = live ? hi : (bf16_t)0.f;
+                    lb[hf][4 * u + e] = live ? (bf16_t)(v - (float)hi) : (bf16_t)0.f;
                 }
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            z[r][tb] = mma16(wa[tb][0], hb[0], f32x4{0.f, 0.f, 0.f, 0.f});
+            z[r][tb] = mma16(wa[tb][0], lb[0], f32x4{0.f, 0.f, 0.f, 0.f});
+            z[r][tb] = mma16(wa[tb][1], lb[1], z[r][tb]);
+            z[r][tb] = mma16(wa[tb][0], hb[0], z[r][tb]);
             z[r][tb] = mma16(wa[tb][1], hb[1], z[r][tb]);
         }
     }

@@ -61,15 +61,20 @@ def test_rgb_tail_matches_two_kernel_path_and_oracle(fused_ctx, case, io):
     assert torch.equal(y1, m.forward(xd))                                                         # deterministic: fixed order of the partial sums
     a, b = y0.float().cpu().numpy(), y1.float().cpu().numpy()
     assert a.shape == (B, H * s, W * s, C)
-    # same products, same bf16 roundings of final_conv1's output; only the order of the fp32 additions differs (tanh output in [-1, 1])
-    tol = 2e-6 if io == "f32" else 2.0 ** -8
-    assert np.abs(a - b).max() <= tol, float(np.abs(a - b).max())
-    ref = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=io == "bf16")
-    e0, e1 = np.abs(a - ref).max(), np.abs(b - ref).max()
+    # Round 4: the fused kernel feeds final_conv1's activation -- which it never stores -- into the 1x1 product as a bf16 hi + lo pair; the
+    # two-kernel path stores and re-reads ONE bf16 value.  Each path is held to the oracle restating ITS roundings (fused_tail), to the
+    # accumulation-order residue the other one shows (tanh output in [-1, 1]); between them lies one bf16 rounding of a 64-channel activation.
+    ref0 = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=io == "bf16", fused_tail=False)
+    ref1 = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=io == "bf16", fused_tail=True)
+    e0, e1 = np.abs(a - ref0).max(), np.abs(b - ref1).max()
     assert e1 <= max(2.0 * e0, 1e-5) + (2.0 ** -8 if io == "bf16" else 0.0), (float(e0), float(e1))
+    assert e0 <= 2e-4 + (2.0 ** -8 if io == "bf16" else 0.0), float(e0)
+    full = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=False, fused_tail=False)
+    keep = M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=False, fused_tail=True)
+    assert np.abs(a - b).max() <= 2.0 * np.abs(full - keep).max() + 1e-5 + (2.0 ** -7 if io == "bf16" else 0.0)     # no further apart than that one rounding
     # a tap on final_conv1 needs that conv's output in memory: the pair then runs as two kernels and the tap holds the activation
     parts = {}
-    M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, parts=parts)
+    M.esrgan_g_forward(x, w, s, 1, dtype=np.float64, attention=False, bf16_storage=True, parts=parts, fused_tail=False)
     y2, taps = m.forward_with_taps(xd, ["final_conv1"])
     assert torch.equal(y2, y0)
     t = taps["final_conv1"].cpu().numpy()
@@ -129,7 +134,7 @@ def test_rgb_tail_falls_back_when_the_workspace_is_too_small(fused_ctx):
     xd = ctx.to_device(x, torch.float32)
     y, ks = kernels_of(ctx, lambda: m.forward(xd))
     assert not any("rgbtail" in k for k in ks)
-    ref = M.esrgan_g_forward(x, w, 2, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=False)
+    ref = M.esrgan_g_forward(x, w, 2, 1, dtype=np.float64, attention=False, bf16_storage=True, bf16_output=False, fused_tail=False)
     assert np.abs(y.cpu().numpy() - ref).max() <= 2e-2
 
 

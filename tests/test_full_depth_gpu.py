@@ -58,10 +58,11 @@ def device_trace(ctx, dtype, w, x, nb=NB, stages=STAGES):
     if dtype == "f32":
         assert torch.equal(y, y2)                 # the same kernels: the same image
     else:
-        # a tap on final_conv1 makes final_conv1 / final_conv2 run as two kernels (the untapped forward folds the RGB conv into final_conv1's
-        # epilogue: another order of the fp32 additions), so the two bf16 images may differ by a flipped rounding here and there ...
+        # a tap on final_conv1 makes final_conv1 / final_conv2 run as two kernels: the activation is stored as ONE bf16 value; the untapped
+        # forward folds the RGB conv into final_conv1's epilogue, where the never-stored activation enters as a bf16 hi + lo pair (round 4),
+        # so the two bf16 images differ by that one rounding of a 64-channel tensor: a flipped output rounding in a fraction of the pixels ...
         d = (y.float() - y2.float()).abs()
-        assert float(d.max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 0.01, (float(d.max()), float((d > 0).float().mean()))
+        assert float(d.max()) <= 2.0 ** -6 and float((d > 0).float().mean()) < 0.25, (float(d.max()), float((d > 0).float().mean()))
         ctx.set_fused(255 & ~4, 0)                 # ... and are the same image when that pair runs as two kernels in both
         try:
             assert torch.equal(y, m.forward(ctx.to_device(x, td)))
@@ -92,8 +93,8 @@ def test_full_depth_bf16_vs_bf16_storage_oracle(ctx):
     x = round_to_bf16(lr_patches(2, seed=45).astype(np.float32))
     got, taps = device_trace(ctx, "bf16", w, x)
     p64, p32 = {}, {}
-    ref = M.esrgan_g_forward(x, w, SCALE, NB, dtype=np.float64, bf16_storage=True, parts=p64)
-    alt = M.esrgan_g_forward(x, w, SCALE, NB, dtype=np.float32, bf16_storage=True, parts=p32)
+    ref = M.esrgan_g_forward(x, w, SCALE, NB, dtype=np.float64, bf16_storage=True, parts=p64, fused_tail=False)
+    alt = M.esrgan_g_forward(x, w, SCALE, NB, dtype=np.float32, bf16_storage=True, parts=p32, fused_tail=False)
     plain = M.esrgan_g_forward(x, w, SCALE, NB, dtype=np.float64)
     print("\nstage                       dev-vs-oracle   oracle self-noise (fp32 vs fp64 arithmetic)")
     for name, _ in STAGES:
@@ -119,7 +120,7 @@ def test_bf16_nb4_one_full_rotation_of_the_concat_buffers(ctx):
     x = round_to_bf16(np.random.default_rng(9).uniform(-1, 1, (3, 40, 28, 3)).astype(np.float32))
     got, taps = device_trace(ctx, "bf16", w, x, nb=nb, stages=stages)
     p64 = {}
-    ref = M.esrgan_g_forward(x, w, SCALE, nb, dtype=np.float64, bf16_storage=True, parts=p64)
+    ref = M.esrgan_g_forward(x, w, SCALE, nb, dtype=np.float64, bf16_storage=True, parts=p64, fused_tail=False)
     for name, _ in stages:
         e = rel_l2(taps[name], p64[name])
         assert e <= 5e-3, (name, e)
