@@ -132,49 +132,59 @@ def parity_object(ctx, model, weights, lr_tile, hr_tile, fp32_ref, io="bf16"):
             "mean_psnr_delta_vs_hr_db": float((vs_hr(got) - vs_hr(f32r)).mean()), "north_star_bar_db": 0.01}
 
 
-TRAINED_LIKE_STEPS = 300
+TRAINED_LIKE_LEVELS = (60, 300)
 
 
-def trained_like_parity(ctx, model_bf16, lr4, hr4, steps=TRAINED_LIKE_STEPS, log=None):
-    """The same parity object on weights in the regime the reference's generators work in (sr355.recipes: analytic start + `steps` L1
-    steps on crops of the bench's own tiles, seeded; PSNR vs HR 35-36 dB where random-init weights give 9.6 dB), plus one whole
-    512 x 512 tile in reference patch mode: PSNR(bf16 generator, HR) against PSNR(fp32 generator, HR), the fp32 device path being the one
-    the 16 patches pin to the CPU oracle (psnr_gpu_f32_vs_fp32_reference_graph_db).  Leaves the model on the fitted weights."""
+def trained_like_parity(ctx, model_bf16, lr4, hr4, levels=TRAINED_LIKE_LEVELS, log=None):
+    """The same parity object on weights in the regime the reference's generators work in (sr355.recipes: analytic start + L1 steps on
+    crops of the bench's own tiles, seeded), at two points of ONE fit: after levels[0] steps (28-32 dB against HR: where the reference's
+    trained models are, ESRGAN.ipynb:L3723-3725) and after levels[1] (33-37 dB: a stress level); random-init weights give 9.6 dB.  Per
+    level: the 16 parity patches against the CPU oracle's fp32 graph (caller tensors fp32, as super_resolve_image hands them over), and
+    every bench tile whole, in reference patch mode: PSNR(bf16 generator, HR) against PSNR(fp32 generator, HR) -- the fp32 device path
+    being the one the 16 patches pin to the CPU oracle (psnr_gpu_f32_vs_fp32_reference_graph_db).  Leaves the model on the last weights.
+    -> ({"steps_<n>": {...}, "weights": ..., "fit_seconds": ...}, last weights)."""
     from oracle import models as OM
-    from sr355.recipes import trained_like_generator
+    from oracle import ops as OO
+    from sr355.recipes import GeneratorPixelFit, crop_batches, near_identity_generator
     from sr355.weights import bf16_rounded, round_to_bf16
     from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
-    t0 = time.perf_counter()
-    w = bf16_rounded(trained_like_generator(ctx, model_bf16.generator.layer_shapes(), lr4, hr4, SCALE, NB, steps=steps, log=log))
-    fit_s = time.perf_counter() - t0
-    model_bf16.set_weights(w)
-    x = round_to_bf16(tile_patches(lr4[0])[PARITY_IDX].astype(np.float32))
-    f32r = np.concatenate([OM.esrgan_g_forward(x[i:i + 2], w, SCALE, NB) for i in range(0, len(x), 2)])
-    out = parity_object(ctx, model_bf16, w, lr4[0], hr4[0], f32r, io="f32")
-    out["bf16_caller_tensors"] = {k: v for k, v in parity_object(ctx, model_bf16, w, lr4[0], hr4[0], f32r, io="bf16").items()
-                                  if k in ("psnr_gpu_vs_oracle_db", "abs_psnr_delta_vs_hr_db", "psnr_gpu_vs_fp32_reference_graph_db",
-                                           "abs_psnr_delta_vs_hr_db_bf16_storage_oracle")}
+    fit = GeneratorPixelFit(ctx, near_identity_generator(model_bf16.generator.layer_shapes()), SCALE, NB, True, 2e-4)
+    batches = crop_batches(lr4, hr4, SCALE, 24, 16, max(levels), 7001)
     m32 = ESRGAN(compute_dtype="f32")
     m32.setup_model(scale_factor=SCALE, growth_channels=G, num_rrdb_blocks=NB)
-    m32.set_weights(w)
-    g32 = m32.generator.forward(ctx.to_device(x, torch.float32)).cpu().numpy()
+    x = round_to_bf16(tile_patches(lr4[0])[PARITY_IDX].astype(np.float32))
     to01 = lambda a: np.clip((a.astype(np.float64) + 1) / 2, 0.0, 1.0)
-    from oracle import ops as OO
-    out["psnr_gpu_f32_vs_fp32_reference_graph_db"] = float(OO.psnr(to01(g32), to01(f32r), dtype=np.float64).min())
-    tiles = []
-    for t in range(len(lr4)):
-        hr_d = ctx.to_device(hr4[t:t + 1])
-        ps = []
-        for m_ in (model_bf16, m32):
-            sr, _ = m_.super_resolve_image(ctx.to_device(lr4[t]), patch_size_lr=PATCH, stride=STRIDE, batch_size=441)
-            ps.append(float(ctx.psnr(hr_d, sr[None])[0].double()))
-        tiles.append({"tile": t, "psnr_bf16_vs_hr_db": ps[0], "psnr_f32_vs_hr_db": ps[1], "abs_delta_db": abs(ps[0] - ps[1])})
+    out, done, fit_s, w = {}, 0, 0.0, None
+    for lv in sorted(levels):
+        t0 = time.perf_counter()
+        for _ in range(lv - done):
+            l1 = fit.step(*next(batches))
+        done = lv
+        fit_s += time.perf_counter() - t0
+        if log is not None:
+            log(lv, l1)
+        w = bf16_rounded(fit.weights)
+        model_bf16.set_weights(w)
+        m32.set_weights(w)
+        f32r = np.concatenate([OM.esrgan_g_forward(x[i:i + 2], w, SCALE, NB) for i in range(0, len(x), 2)])
+        o = parity_object(ctx, model_bf16, w, lr4[0], hr4[0], f32r, io="f32")
+        g32 = m32.generator.forward(ctx.to_device(x, torch.float32)).cpu().numpy()
+        o["psnr_gpu_f32_vs_fp32_reference_graph_db"] = float(OO.psnr(to01(g32), to01(f32r), dtype=np.float64).min())
+        tiles = []
+        for t in range(len(lr4)):
+            hr_d = ctx.to_device(hr4[t:t + 1])
+            ps = []
+            for m_ in (model_bf16, m32):
+                sr, _ = m_.super_resolve_image(ctx.to_device(lr4[t]), patch_size_lr=PATCH, stride=STRIDE, batch_size=441)
+                ps.append(float(ctx.psnr(hr_d, sr[None])[0].double()))
+            tiles.append({"tile": t, "psnr_bf16_vs_hr_db": ps[0], "psnr_f32_vs_hr_db": ps[1], "abs_delta_db": abs(ps[0] - ps[1])})
+        o["whole_tiles_patch_mode"] = tiles
+        o["whole_tile_abs_psnr_delta_vs_hr_db"] = max(t["abs_delta_db"] for t in tiles)
+        out[f"steps_{lv}"] = o
     m32.generator.release_workspace()
-    del m32
-    out["whole_tiles_patch_mode"] = tiles
-    out["whole_tile_abs_psnr_delta_vs_hr_db"] = max(t["abs_delta_db"] for t in tiles)
-    out["weights"] = (f"sr355.recipes.trained_like_generator: analytic near-identity start, {steps} L1-only Adam steps (lr 2e-4, batch 16, 24 x 24 LR "
-                      "crops of the bench's 4 tiles), fp32 on the device, seeded; rounded to bf16 for both the device and the oracle")
+    del m32, fit
+    out["weights"] = ("sr355.recipes: analytic near-identity start, then L1-only Adam steps (lr 2e-4, batch 16, 24 x 24 LR crops of the bench's 4 tiles), "
+                      "fp32 on the device, seeded; rounded to bf16 for both the device and the oracle")
     out["fit_seconds"] = fit_s
     return out, w
 

@@ -28,32 +28,44 @@ def fitted(ctx):
     m.generator.release_workspace()
 
 
+LEVELS = [f"steps_{n}" for n in B.TRAINED_LIKE_LEVELS]
+
+
 def test_recipe_reaches_the_trained_regime(fitted):
-    out = fitted[0]
-    lo, hi = out["psnr_fp32_reference_graph_vs_hr_db"]
-    print(f"\nPSNR(fp32 oracle, HR) on the 16 parity patches: {lo:.2f} .. {hi:.2f} dB; whole tiles: "
-          + ", ".join(f"{t['psnr_f32_vs_hr_db']:.2f}" for t in out["whole_tiles_patch_mode"]))
-    assert lo >= 25.0, lo                                                   # the verdict's bar; the reference's own models: 28.8-31.3 dB
-    assert min(t["psnr_f32_vs_hr_db"] for t in out["whole_tiles_patch_mode"]) >= 25.0
+    for lv in LEVELS:
+        out = fitted[0][lv]
+        lo, hi = out["psnr_fp32_reference_graph_vs_hr_db"]
+        print(f"\n{lv}: PSNR(fp32 oracle, HR) on the 16 parity patches: {lo:.2f} .. {hi:.2f} dB; whole tiles: "
+              + ", ".join(f"{t['psnr_f32_vs_hr_db']:.2f}" for t in out["whole_tiles_patch_mode"]))
+        assert lo >= 25.0, lo                                               # the verdict's bar; the reference's own models: 28.8-31.3 dB
+        assert min(t["psnr_f32_vs_hr_db"] for t in out["whole_tiles_patch_mode"]) >= 25.0
 
 
 def test_bf16_parity_on_the_16_bench_patches(fitted):
-    out = fitted[0]
-    print(f"\n|dPSNR vs HR| bf16 device vs fp32 oracle: {out['abs_psnr_delta_vs_hr_db']:.5f} dB (mean {out['mean_psnr_delta_vs_hr_db']:+.5f}); "
-          f"PSNR(gpu, fp32 oracle) {out['psnr_gpu_vs_fp32_reference_graph_db']:.2f} dB; PSNR(gpu, bf16-storage oracle) {out['psnr_gpu_vs_oracle_db']:.2f} dB; "
-          f"bf16 caller tensors: {out['bf16_caller_tensors']}")
-    assert out["psnr_gpu_f32_vs_fp32_reference_graph_db"] >= 100.0          # the fp32 device path IS the oracle's graph (pins the whole-tile figure below)
-    assert out["abs_psnr_delta_vs_hr_db"] <= 0.01, out["abs_psnr_delta_vs_hr_db"]                      # north star, product path (fp32 caller tensors)
-    assert out["abs_psnr_delta_vs_hr_db_bf16_storage_oracle"] <= 0.005
-    assert out["psnr_gpu_vs_fp32_reference_graph_db"] >= 64.0
-    assert out["psnr_gpu_vs_oracle_db"] >= 70.0                              # like for like: what is left is accumulation order
+    """North star: |PSNR(gpu, HR) - PSNR(cpu reference, HR)| <= 0.01 dB, per patch, in the regime the reference's models work in (first
+    level).  What bounds it is the bf16 path's noise floor against the fp32 graph, ~68 dB on these weights (five serial bf16 operand
+    roundings of the image-carrying tensors behind the trunk): at 30 dB that is 1.6e-4 of the image's own MSE; at
+    the stress level (33-37 dB) 1e-3, where a 6 % correlation between the two errors is already worth 0.01 dB -- the bound there is the
+    floor itself and twice the bar."""
+    for lv in LEVELS:
+        out = fitted[0][lv]
+        print(f"\n{lv}: |dPSNR vs HR| bf16 device vs fp32 oracle: {out['abs_psnr_delta_vs_hr_db']:.5f} dB (mean {out['mean_psnr_delta_vs_hr_db']:+.5f}); "
+              f"PSNR(gpu, fp32 oracle) {out['psnr_gpu_vs_fp32_reference_graph_db']:.2f} dB; PSNR(gpu, bf16-storage oracle) {out['psnr_gpu_vs_oracle_db']:.2f} dB")
+        assert out["psnr_gpu_f32_vs_fp32_reference_graph_db"] >= 100.0      # the fp32 device path IS the oracle's graph (pins the whole-tile figures)
+        assert out["psnr_gpu_vs_fp32_reference_graph_db"] >= 66.0           # the floor
+        assert out["psnr_gpu_vs_oracle_db"] >= 70.0                          # like for like: what is left is accumulation order
+        assert out["abs_psnr_delta_vs_hr_db_bf16_storage_oracle"] <= 0.005
+    assert fitted[0][LEVELS[0]]["abs_psnr_delta_vs_hr_db"] <= 0.01
+    assert fitted[0][LEVELS[1]]["abs_psnr_delta_vs_hr_db"] <= 0.02
 
 
 def test_bf16_parity_on_whole_tiles_in_patch_mode(fitted):
-    out = fitted[0]
-    for t in out["whole_tiles_patch_mode"]:
-        print(f"\ntile {t['tile']}: PSNR vs HR bf16 {t['psnr_bf16_vs_hr_db']:.4f} dB, fp32 {t['psnr_f32_vs_hr_db']:.4f} dB, |delta| {t['abs_delta_db']:.5f}")
-    assert out["whole_tile_abs_psnr_delta_vs_hr_db"] <= 0.01
+    """Every bench tile whole (441 overlapping patches, averaged: ESRGAN_model.py:903-921), at both levels: <= 0.01 dB."""
+    for lv in LEVELS:
+        out = fitted[0][lv]
+        for t in out["whole_tiles_patch_mode"]:
+            print(f"\n{lv} tile {t['tile']}: PSNR vs HR bf16 {t['psnr_bf16_vs_hr_db']:.4f} dB, fp32 {t['psnr_f32_vs_hr_db']:.4f} dB, |delta| {t['abs_delta_db']:.5f}")
+        assert out["whole_tile_abs_psnr_delta_vs_hr_db"] <= 0.01
 
 
 def test_recipe_is_deterministic(ctx):
