@@ -529,6 +529,9 @@ int sr_init(int device_id, sr_ctx** out) {
     sr_ctx* c = new sr_ctx();
     c->device = device_id;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return SR_ERR_HIP; }
+    c->zero_page = c->dalloc(sr_ctx::ZERO_PAGE_BYTES);
+    if (!c->zero_page) { sr_destroy(c); return SR_ERR_OOM; }
+    if (hipMemset(c->zero_page, 0, sr_ctx::ZERO_PAGE_BYTES) != hipSuccess) { sr_destroy(c); return SR_ERR_HIP; }
     *out = c;
     return SR_OK;
 }

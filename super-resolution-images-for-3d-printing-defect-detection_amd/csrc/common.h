@@ -52,7 +52,9 @@ struct sr_ctx {
     Arena attn_kn;                // attention: per-key-group largest key norm (stream-ordered reuse)
     Arena dev_w, dev_b, dev_x;    // sr_conv2d_dev: packed weights / padded bias / padded input of the call in flight (stream-ordered reuse)
     void* arena(Arena& a, size_t bytes, hipStream_t st);   // grow-only; growing waits for `st` first
-    void* zero_page = nullptr;    // 32 KiB of zeros (DMA source of padding rows in dense_fused.hip)
+    static constexpr int ZERO_PAGE_BYTES = 32768;
+    void* zero_page = nullptr;    // ZERO_PAGE_BYTES of zeros (DMA source of padding rows / halo pixels in dense_fused.hip, conv_stream.hip): allocated and cleared
+                                  // synchronously in sr_init, so that no launch on any stream can see it before it is zero
     int num_cus = 0;
     int cu_count();               // compute units of the device (queried once)
     int chain_mask = 255;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid, bit 5: conv1 of a dense block on the streaming kernel, bit 6: a 2x2 max-pool inside the conv in front of it, bit 7: 64-input-channel 3x3 convs on the persistent kernel of conv_stream.hip (sr_debug_set_fused; default all)

@@ -199,11 +199,7 @@ bool conv_stream_supported(const ConvWeights& w, const convk::ConvParams& p) {
 }
 
 int conv_stream_launch(sr_ctx* ctx, const ConvWeights& w, const convk::ConvParams& p0, hipStream_t st) {
-    if (!ctx->zero_page) {
-        ctx->zero_page = ctx->dalloc(32768);
-        if (!ctx->zero_page) return SR_ERR_OOM;
-        SR_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, 32768, st));
-    }
+    if (!ctx->zero_page) return ctx->fail(SR_ERR_STATE, "context has no zero page");      // sr_init allocates and clears it
     StreamParams sp;
     sp.c = p0;
     sp.zero = static_cast<const char*>(ctx->zero_page);

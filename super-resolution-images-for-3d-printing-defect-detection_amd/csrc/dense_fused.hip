@@ -61,7 +61,7 @@ constexpr int ROWB = 3072;             // one LDS / HBM row of a chunk: 48 pixel
 constexpr int NSTG = 11;               // staged rows per chunk: stream rows [8s-2, 8s+9)
 constexpr int STGB = NSTG * ROWB;
 constexpr int WINR = 10;               // ring rows of layer 0's output: [8s-2, 8s+8)
-constexpr int ZERO_PAGE_BYTES = 32768;
+constexpr int ZERO_PAGE_BYTES = sr_ctx::ZERO_PAGE_BYTES;
 
 template <int NB0, int NB1, int MODE> struct ChainLds {
     static constexpr int WSLOT = (NB0 + NB1) * 3 * 1024;
@@ -930,11 +930,7 @@ bool conv1_stream_supported(const ConvWeights& w, const TensorView& in, int W) {
 int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st) {
     if (!conv1_stream_supported(w, in, W)) return ctx->fail(SR_ERR_INVALID, "streaming conv1: needs a 64 -> 32 bf16 3x3 conv on a 48-pixel-wide row-blocked buffer");
     if (B <= 0 || H <= 0) return ctx->fail(SR_ERR_INVALID, "streaming conv1: empty tensor");
-    if (!ctx->zero_page) {
-        ctx->zero_page = ctx->dalloc(ZERO_PAGE_BYTES);
-        if (!ctx->zero_page) return SR_ERR_OOM;
-        SR_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, ZERO_PAGE_BYTES, st));
-    }
+    if (!ctx->zero_page) return ctx->fail(SR_ERR_STATE, "context has no zero page");      // sr_init allocates and clears it
     int ncu = ctx->cu_count();
     if (ctx->chain_max_wgs > 0 && ctx->chain_max_wgs < ncu) ncu = ctx->chain_max_wgs;
     Conv1Params p;
@@ -973,13 +969,9 @@ int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H
     const bool tail = w.nb1 == 4;
     if (tail && (!out.p || !out.blk || out.coff != 0 || out.cs % 32 != 0 || alpha == 0.f)) return ctx->fail(SR_ERR_INVALID, "fused dense-block tail: bad destination view");
     if (skip_o.p && (!skip_o.blk || skip_o.coff != 0 || skip_o.cs % 32 != 0)) return ctx->fail(SR_ERR_INVALID, "fused dense-block tail: bad skip view");
-    if (!ctx->zero_page) {
-        // separator / out-of-stream rows are staged from here with the same chunk offset as real rows: (EXT - 1) * 3 KiB + one 3 KiB row
-        static_assert(ZERO_PAGE_BYTES >= 6 * ROWB, "zero page covers every chunk offset");
-        ctx->zero_page = ctx->dalloc(ZERO_PAGE_BYTES);
-        if (!ctx->zero_page) return SR_ERR_OOM;
-        SR_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, ZERO_PAGE_BYTES, st));
-    }
+    // separator / out-of-stream rows are staged from the zero page with the same chunk offset as real rows: (EXT - 1) * 3 KiB + one 3 KiB row
+    static_assert(ZERO_PAGE_BYTES >= 6 * ROWB, "zero page covers every chunk offset");
+    if (!ctx->zero_page) return ctx->fail(SR_ERR_STATE, "context has no zero page");      // sr_init allocates and clears it
     int ncu = ctx->num_cus;
     if (ncu <= 0) {
         hipDeviceProp_t prop;
