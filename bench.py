@@ -212,11 +212,22 @@ def launch_ranks(n, argv):
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (SR355_ONE_DEVICE=1 rehearses the N-rank plumbing on one GPU over gloo)")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.Popen(launch_command(n, argv, free_port()), env=env, stdout=subprocess.PIPE, text=True)
-    for ln in proc.stdout:                    # rank 0's line (and nothing else) goes to stdout; the ranks' stderr passes straight through
-        sys.stdout.write(ln)
-        sys.stdout.flush()
-    return proc.wait()
+    # free_port() closes its socket before torchrun binds the number, so another process can take it in between: when the children die
+    # without rank 0 having printed its line (a failed rendezvous prints nothing), try once more on a fresh port
+    rc = 1
+    for attempt in range(2):
+        proc = subprocess.Popen(launch_command(n, argv, free_port()), env=env, stdout=subprocess.PIPE, text=True)
+        printed = False
+        for ln in proc.stdout:                # rank 0's line (and nothing else) goes to stdout; the ranks' stderr passes straight through
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            printed = printed or bool(ln.strip())
+        rc = proc.wait()
+        if rc == 0 or printed:
+            break
+        print(f"[bench] the {n}-rank launch exited with {rc} before printing a line" + ("; retrying once on another port" if attempt == 0 else ""),
+              file=sys.stderr, flush=True)
+    return rc
 
 
 def roofline_object(dom, traffic, instrumented_ms_per_step, clock_mhz=None):
@@ -269,6 +280,8 @@ def main():
         args.chunk = 441 * max(1, args.tiles_per_call)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))

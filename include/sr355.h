@@ -167,10 +167,12 @@ int  sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int 
  * loading_methods.py:147).  dtype f32: float path; u8: OpenCV fixed-point path. */
 int  sr_bicubic(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C,
                 int outH, int outW, void* y, void* stream);
-/* cv2.resize(x, (outW, outH), interpolation=code) with OpenCV's codes INTER_LINEAR = 1, INTER_CUBIC = 2, INTER_AREA = 3,
- * INTER_LANCZOS4 = 4: classic_algorithms.py:7-21 (interpolate_bilinear / _bicubic / _area / _lanczos) and the per-file codes of
- * interpolation_map.pkl in load_dataset_as_patches(mode="srcnn") (loading_methods.py:131-148).  f32: float path; u8: OpenCV's
- * 11-bit fixed-point path (INTER_AREA shrinking: f32 only). */
+/* cv2.resize(x, (outW, outH), interpolation=code) with OpenCV's codes INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2,
+ * INTER_AREA = 3, INTER_LANCZOS4 = 4: classic_algorithms.py:7-21 (interpolate_bilinear / _bicubic / _area / _lanczos) and the
+ * per-file codes of interpolation_map.pkl in load_dataset_as_patches(mode="srcnn") (loading_methods.py:131-148, which hands an
+ * integer entry of the map to cv2.resize as it is).  f32: float path; u8: OpenCV's 11-bit fixed-point path; uint8 INTER_AREA
+ * shrinking: integer cell sums for whole-number factors ((sum + 2) >> 2 for 2 x 2, a rounded float product otherwise), the
+ * float taps rounded half to even for the others.  Any other code: SR_ERR_INVALID. */
 int  sr_resize(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C,
                int outH, int outW, int interpolation, void* y, void* stream);
 /* tf.image.psnr / tf.image.ssim(max_val) (metrics.py:3-7): a,b f32 [B,H,W,C] -> out f32 [B] (device). */

@@ -290,7 +290,7 @@ def bicubic_resize_u8(img, out_h, out_w):
 # pass into float rows, then a vertical pass -- with the coefficient formulas of resizeGeneric / interpolateLanczos4 /
 # computeResizeAreaTab.
 # --------------------------------------------------------------------------------------
-INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 1, 2, 3, 4
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
 
 
 def lanczos4_coeffs(x):
@@ -373,10 +373,26 @@ def resize_axis_taps(n_src, n_dst, interpolation, area_up=False):
     raise ValueError(f"interpolation code {interpolation}")
 
 
+def nearest_indices(n_src, n_dst):
+    """OpenCV resizeNN: source index of destination index d = min(cvFloor(d * (1 / (n_dst / n_src))), n_src - 1), in double."""
+    ifx = 1.0 / (float(n_dst) / float(n_src))
+    return np.minimum(np.floor(np.arange(n_dst, dtype=np.float64) * ifx).astype(np.int64), n_src - 1)
+
+
+def cv_resize_nearest(img, out_h, out_w):
+    """cv2.resize(..., interpolation=INTER_NEAREST), any dtype, [H,W,C] or [B,H,W,C]: a pure gather."""
+    img = np.asarray(img)
+    H, W = img.shape[-3], img.shape[-2]
+    iy, ix = nearest_indices(H, out_h), nearest_indices(W, out_w)
+    return img[..., iy, :, :][..., :, ix, :]
+
+
 def cv_resize(img, out_h, out_w, interpolation):
     """cv2.resize(img, (out_w, out_h), interpolation=...) for float32 images [H,W,C] / [B,H,W,C]: horizontal pass into float
     rows, then the vertical pass (taps in ascending source order), no clipping."""
     img = np.asarray(img, np.float32)
+    if interpolation == INTER_NEAREST:
+        return cv_resize_nearest(img, out_h, out_w)
     squeeze = img.ndim == 3
     if squeeze:
         img = img[None]
@@ -400,9 +416,13 @@ def cv_resize_u8(img, out_h, out_w, interpolation):
     img = np.asarray(img)
     assert img.dtype == np.uint8
     H, W, C = img.shape
+    if interpolation == INTER_NEAREST:
+        return cv_resize_nearest(img, out_h, out_w)
+    if interpolation == INTER_LINEAR and W == 2 * out_w and H == 2 * out_h:
+        interpolation = INTER_AREA                                 # OpenCV's resize(): bilinear halving IS the 2 x 2 box mean
     area_up = interpolation == INTER_AREA and not (out_w <= W and out_h <= H)
     if interpolation == INTER_AREA and not area_up:
-        raise NotImplementedError("uint8 INTER_AREA shrinking is not restated")
+        return cv_resize_area_shrink_u8(img, out_h, out_w)
     ix, wx = resize_axis_taps(W, out_w, interpolation, area_up)
     iy, wy = resize_axis_taps(H, out_h, interpolation, area_up)
     iwx = np.clip(np.rint(wx * np.float32(2048.0)), -32768, 32767).astype(np.int64)
@@ -420,6 +440,27 @@ def cv_resize_u8(img, out_h, out_w, interpolation):
             out += tmp[iy[:, k]] * iwy[:, k, None, None]
         out = (out + (1 << 21)) >> 22
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def cv_resize_area_shrink_u8(img, out_h, out_w):
+    """uint8 INTER_AREA, shrinking both ways (classic_algorithms.py:15-17 feeds uint8 images; OpenCV imgproc/resize.cpp).
+    Whole-number factors on both axes (resizeAreaFast_): the integer sum over the iy x ix cell, then (sum + 2) >> 2 for the 2 x 2
+    cell of 1-, 3- and 4-channel images (ResizeAreaFastVec) and saturate_cast<uchar>(sum * (1.f / area)) -- a float product,
+    rounded half to even -- otherwise.  Any other factor (resizeArea_<uchar, float>): the float path's taps and order of
+    operations on the uint8 values (per source row: sum of S * alpha in ascending source order; then sum of beta * row), the
+    float sum rounded half to even and saturated."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3
+    H, W, C = img.shape
+    if W % out_w == 0 and H % out_h == 0:
+        fy, fx = H // out_h, W // out_w
+        sums = img.astype(np.int64).reshape(out_h, fy, out_w, fx, C).sum(axis=(1, 3))
+        if fy == 2 and fx == 2 and C in (1, 3, 4):
+            return ((sums + 2) >> 2).astype(np.uint8)
+        v = np.rint(sums.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(fy * fx)))
+        return np.clip(v, 0, 255).astype(np.uint8)
+    v = np.rint(cv_resize(img.astype(np.float32), out_h, out_w, INTER_AREA))
+    return np.clip(v, 0, 255).astype(np.uint8)
 
 
 # --------------------------------------------------------------------------------------

@@ -817,17 +817,94 @@ __global__ void resize_apply_u8_kernel(const uint8_t* x, int B, int H, int W, in
     }
 }
 
+// INTER_NEAREST (OpenCV resizeNN): source index = min(cvFloor(d * (1 / (n_dst / n_src))), n_src - 1) in double; a gather of ES-byte elements
+template <typename E>
+__global__ void resize_nearest_kernel(const E* x, int B, int H, int W, int C, int oH, int oW, double ify, double ifx, E* y) {
+    const int64_t n = (int64_t)B * oH * oW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % oW); t /= oW;
+        const int oy = (int)(t % oH);
+        const int b = (int)(t / oH);
+        const int sx = min((int)floor(__dmul_rn((double)ox, ifx)), W - 1), sy = min((int)floor(__dmul_rn((double)oy, ify)), H - 1);
+        y[i] = x[(((int64_t)b * H + sy) * W + sx) * C + c];
+    }
+}
+
+// uint8 INTER_AREA by whole-number factors on both axes (OpenCV resizeAreaFast_<uchar, int, ...>): integer sum over the fy x fx cell, then
+// (sum + 2) >> 2 for the 2 x 2 cell of 1-, 3- and 4-channel images (ResizeAreaFastVec), saturate_cast<uchar>(sum * (1.f / area)) otherwise
+// (a float product, rounded half to even).
+__global__ void resize_area_fast_u8_kernel(const uint8_t* x, int B, int H, int W, int C, int oH, int oW, int fy, int fx, uint8_t* y) {
+    const int64_t n = (int64_t)B * oH * oW * C;
+    const bool shift2 = fy == 2 && fx == 2 && (C == 1 || C == 3 || C == 4);
+    const float scale = 1.f / (float)(fy * fx);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % oW); t /= oW;
+        const int oy = (int)(t % oH);
+        const int b = (int)(t / oH);
+        int sum = 0;
+        for (int j = 0; j < fy; ++j) {
+            const uint8_t* row = x + (((int64_t)b * H + oy * fy + j) * W + (int64_t)ox * fx) * C + c;
+            for (int k = 0; k < fx; ++k) sum += row[(int64_t)k * C];
+        }
+        y[i] = shift2 ? (uint8_t)((sum + 2) >> 2) : (uint8_t)fminf(fmaxf(rintf(__fmul_rn((float)sum, scale)), 0.f), 255.f);
+    }
+}
+
+// uint8 INTER_AREA by any other shrink factor (OpenCV resizeArea_<uchar, float>): the float path's taps and order of operations on the uint8
+// values, the float sum rounded half to even and saturated.
+__global__ void resize_apply_area_u8_kernel(const uint8_t* x, int B, int H, int W, int C, int oH, int oW, int TX, int TY, const int* ix, const float* wx,
+                                            const int* iy, const float* wy, uint8_t* y) {
+    const int64_t n = (int64_t)B * oH * oW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % oW); t /= oW;
+        const int oy = (int)(t % oH);
+        const int b = (int)(t / oH);
+        float acc = 0.f;
+        for (int j = 0; j < TY; ++j) {
+            const float wyj = wy[oy * TY + j];
+            const uint8_t* row = x + ((int64_t)b * H + iy[oy * TY + j]) * W * C + c;
+            float r = 0.f;
+            for (int k = 0; k < TX; ++k) r = __fadd_rn(r, __fmul_rn((float)row[(int64_t)ix[ox * TX + k] * C], wx[ox * TX + k]));
+            acc = __fadd_rn(acc, __fmul_rn(r, wyj));
+        }
+        y[i] = (uint8_t)fminf(fmaxf(rintf(acc), 0.f), 255.f);
+    }
+}
+
 int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, int outH, int outW, int interp, void* y, hipStream_t st) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || outH <= 0 || outW <= 0) return ctx->fail(SR_ERR_INVALID, "resize: empty tensor");
     if (dtype != SR_DTYPE_F32 && dtype != SR_DTYPE_U8) return ctx->fail(SR_ERR_INVALID, "resize: dtype must be f32 or u8");
     if (interp == 2) return bicubic_launch(ctx, x, dtype, B, H, W, C, outH, outW, y, dtype, C, st);
-    if (interp != 1 && interp != 3 && interp != 4) return ctx->fail(SR_ERR_INVALID, "resize: interpolation must be INTER_LINEAR (1), INTER_CUBIC (2), INTER_AREA (3) or INTER_LANCZOS4 (4)");
+    const int64_t n_out = (int64_t)B * outH * outW * C;
+    if (interp == 0) {
+        const double ify = 1.0 / ((double)outH / (double)H), ifx = 1.0 / ((double)outW / (double)W);
+        if (dtype == SR_DTYPE_F32)
+            hipLaunchKernelGGL(resize_nearest_kernel<float>, dim3(grid_for(n_out)), dim3(256), 0, st, static_cast<const float*>(x), B, H, W, C, outH, outW, ify, ifx, static_cast<float*>(y));
+        else
+            hipLaunchKernelGGL(resize_nearest_kernel<uint8_t>, dim3(grid_for(n_out)), dim3(256), 0, st, static_cast<const uint8_t*>(x), B, H, W, C, outH, outW, ify, ifx, static_cast<uint8_t*>(y));
+        SR_HIP(ctx, hipGetLastError());
+        return SR_OK;
+    }
+    if (interp != 1 && interp != 3 && interp != 4)
+        return ctx->fail(SR_ERR_INVALID, "resize: interpolation must be INTER_NEAREST (0), INTER_LINEAR (1), INTER_CUBIC (2), INTER_AREA (3) or INTER_LANCZOS4 (4)");
+    if (interp == 1 && W == 2 * outW && H == 2 * outH) interp = 3;          // OpenCV's resize(): bilinear halving IS the 2 x 2 box mean
     const bool shrink_both = outW <= W && outH <= H;
     const int area_up = interp == 3 && !shrink_both;
+    if (dtype == SR_DTYPE_U8 && interp == 3 && !area_up && W % outW == 0 && H % outH == 0) {
+        hipLaunchKernelGGL(resize_area_fast_u8_kernel, dim3(grid_for(n_out)), dim3(256), 0, st, static_cast<const uint8_t*>(x), B, H, W, C, outH, outW, H / outH, W / outW,
+                           static_cast<uint8_t*>(y));
+        SR_HIP(ctx, hipGetLastError());
+        return SR_OK;
+    }
     auto taps = [&](int ns, int nd) { return interp == 4 ? 8 : (interp == 3 && !area_up) ? (int)ceil((double)ns / nd) + 2 : 2; };
     const int TX = taps(W, outW), TY = taps(H, outH);
     if (TX > RS_MAXT || TY > RS_MAXT) return ctx->fail(SR_ERR_INVALID, "resize: INTER_AREA shrink factor above 14 is not supported");
-    if (dtype == SR_DTYPE_U8 && interp == 3 && !area_up) return ctx->fail(SR_ERR_INVALID, "resize: uint8 INTER_AREA shrinking is not built");
     const size_t nx = (size_t)outW * TX, ny = (size_t)outH * TY, need = (nx + ny) * 12;
     if (need > ctx->tab_cap) {
         if (ctx->tab_buf) { SR_HIP(ctx, hipDeviceSynchronize()); ctx->dfree(ctx->tab_buf); ctx->tab_buf = nullptr; ctx->tab_cap = 0; }
@@ -847,6 +924,9 @@ int resize_launch(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, in
     if (dtype == SR_DTYPE_F32)
         hipLaunchKernelGGL(resize_apply_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const float*>(x), B, H, W, C, outH, outW, TX, TY, ix, wx, iy, wy,
                            static_cast<float*>(y));
+    else if (interp == 3 && !area_up)
+        hipLaunchKernelGGL(resize_apply_area_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const uint8_t*>(x), B, H, W, C, outH, outW, TX, TY, ix, wx, iy, wy,
+                           static_cast<uint8_t*>(y));
     else
         hipLaunchKernelGGL(resize_apply_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const uint8_t*>(x), B, H, W, C, outH, outW, TX, TY, ix, iwx, iy, iwy,
                            static_cast<uint8_t*>(y));

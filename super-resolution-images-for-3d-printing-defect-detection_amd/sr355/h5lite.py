@@ -383,7 +383,11 @@ def write_h5(path, datasets, attrs=None, leaf_k=64):
 
 def save_keras_weights(path, weights, model_name=None):
     """{layer: (kernel, bias)} -> a file in Keras' `model.save` weight layout: /model_weights/<layer>/<layer>/kernel:0 and bias:0 with the
-    `layer_names` / `weight_names` / `backend` / `keras_version` attributes Keras' own loader walks (hdf5_format.load_weights_from_hdf5_group)."""
+    `layer_names` / `weight_names` / `backend` / `keras_version` attributes Keras' own loader walks (hdf5_format.load_weights_from_hdf5_group).
+    WEIGHTS ONLY, FLAT NAMES: the file holds no `model_config` / `training_config`, so the reference's `load_model(path)` (ESRGAN_model.py:143-149,
+    SRCNN_model.py:35) cannot open it; it is read by this package's loader and by Keras' `model.load_weights(path)` on a model whose layers carry
+    these flat names.  The reference's discriminator wraps its layers in tfa SpectralNormalization (groups `spectral_normalization*/...` with a
+    `sn_u` vector) and its classifier nests the base under `vgg16/`: neither nesting is emitted here."""
     ds, at = {}, {"/model_weights": {"layer_names": np.array([n.encode() for n in weights], dtype="S"), "backend": np.array(b"tensorflow"),
                                      "keras_version": np.array(b"2.10.0")}}
     for n, (k, b) in weights.items():

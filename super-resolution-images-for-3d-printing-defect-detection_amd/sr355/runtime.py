@@ -194,14 +194,19 @@ class Context:
                                        self.stream()))
         return y
 
-    INTERPOLATIONS = {"INTER_LINEAR": 1, "INTER_CUBIC": 2, "INTER_AREA": 3, "INTER_LANCZOS4": 4}
+    INTERPOLATIONS = {"INTER_NEAREST": 0, "INTER_LINEAR": 1, "INTER_CUBIC": 2, "INTER_AREA": 3, "INTER_LANCZOS4": 4, "INTER_LINEAR_EXACT": 5}
 
     def resize(self, x, out_h, out_w, interpolation="INTER_CUBIC"):
-        """cv2.resize(x, (out_w, out_h), interpolation): x [B,H,W,C] f32 or u8 tensor; interpolation = OpenCV name or code."""
+        """cv2.resize(x, (out_w, out_h), interpolation): x [B,H,W,C] f32 or u8 tensor; interpolation = OpenCV name or code
+        (INTER_NEAREST 0, INTER_LINEAR 1, INTER_CUBIC 2, INTER_AREA 3, INTER_LANCZOS4 4; INTER_LINEAR_EXACT 5 on float images, where
+        OpenCV itself falls back to INTER_LINEAR).  Codes cv2.resize rejects, and the two it accepts that are not restated here
+        (INTER_NEAREST_EXACT 6; INTER_LINEAR_EXACT on uint8), raise ValueError -- cv2.error where the reference runs."""
         code = self.INTERPOLATIONS.get(interpolation, interpolation)
-        if code not in (1, 2, 3, 4):
-            raise ValueError(f"unsupported interpolation {interpolation!r}")
         _check_tensor(self, x, "resize input", (torch.float32, torch.uint8))
+        if code == 5 and x.dtype == torch.float32:
+            code = 1
+        if isinstance(code, bool) or not isinstance(code, (int, np.integer)) or int(code) not in (0, 1, 2, 3, 4):
+            raise ValueError(f"unsupported interpolation {interpolation!r}")
         B, H, W, Cx = x.shape
         y = self.empty((B, out_h, out_w, Cx), x.dtype)
         self.check(self.lib.sr_resize(self.h, x.data_ptr(), dtype_code(x.dtype), B, H, W, Cx, int(out_h), int(out_w), int(code), y.data_ptr(),

@@ -105,3 +105,26 @@ def test_parity_patches_cover_the_tile_and_have_hr_counterparts(bench):
     assert hp.shape == (16, 192, 192, 3)
     r, c = divmod(bench.PARITY_IDX[5], 21)
     assert hp[5, 0, 0, 0] == hr[r * 96, c * 96, 0] and r * 96 + 192 <= 2048 and c * 96 + 192 <= 2048
+
+
+def test_launcher_retries_once_when_the_children_die_before_printing(bench, monkeypatch, capsys):
+    """the port from free_port() can be taken between closing the probe socket and torchrun binding it; a launch that dies
+    without rank 0's line is repeated once on a fresh port, one that printed is not."""
+    monkeypatch.setattr(bench.torch.cuda, "is_initialized", lambda: False)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    calls = []
+
+    def cmd(n, argv, port):
+        calls.append(port)
+        if len(calls) == 1:
+            return [bench.sys.executable, "-c", "import sys; sys.exit(1)"]
+        return [bench.sys.executable, "-c", "print('{\"n_gpus\": 2}')"]
+    monkeypatch.setattr(bench, "launch_command", cmd)
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
+    assert len(calls) == 2 and '"n_gpus": 2' in capsys.readouterr().out
+
+
+def test_steps_below_one_is_refused(bench, monkeypatch):
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--steps", "0"])
+    with pytest.raises(SystemExit):
+        bench.main()

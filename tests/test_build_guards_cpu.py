@@ -81,3 +81,18 @@ _Zkernel_conv3_rows_kernel_loop:
     k = C.parse_kernels(loop)
     probs = C.check_kernel("loop", k["_Zkernel_conv3_rows_kernel_loop"])
     assert len(probs) == 1 and "v12, v4" in probs[0]          # the loop body is clean (wait first); the exit path is not
+
+
+def test_checker_allows_overlapping_destinations_only_among_in_order_loads():
+    """a load into the destination of an in-flight load is harmless only while both are global_ / buffer_ loads (one in-order
+    return queue, the one vmcnt counts); with a flat_ load on either side the overlap is reported."""
+    C = _checker()
+
+    def probs(body):
+        src = "\n_Zkernel_conv3_rows_kernel_t:\n" + body + "\ts_waitcnt vmcnt(0)\n\ts_endpgm\n.Lfunc_end0:\n"
+        return C.check_kernel("t", C.parse_kernels(src)["_Zkernel_conv3_rows_kernel_t"])
+
+    assert probs("\tglobal_load_dwordx4 v[4:7], v[0:1], off\n\tglobal_load_dwordx4 v[4:7], v[2:3], off\n") == []
+    assert probs("\tglobal_load_dwordx4 v[4:7], v[0:1], off\n\tbuffer_load_dwordx4 v[4:7], v2, s[0:3], 0 offen\n") == []
+    assert len(probs("\tflat_load_dwordx4 v[4:7], v[0:1]\n\tglobal_load_dwordx4 v[4:7], v[2:3], off\n")) == 1
+    assert len(probs("\tglobal_load_dwordx4 v[4:7], v[0:1], off\n\tflat_load_dwordx4 v[4:7], v[2:3]\n")) == 1

@@ -346,7 +346,44 @@ def test_resize_u8_bit_exact(ctx, interp):
         ref = O.cv_resize_u8(x[0], out[0], out[1], code)
         got = ctx.resize(ctx.to_device(x, torch.uint8), out[0], out[1], interp).cpu().numpy()[0]
         assert np.array_equal(got, ref), (shape, out, int(np.abs(got.astype(int) - ref.astype(int)).max()))
-    with pytest.raises(ValueError):
-        ctx.resize(ctx.to_device(x, torch.uint8), 4, 4, "INTER_AREA")          # uint8 shrinking area: not built
-    with pytest.raises(ValueError):
-        ctx.resize(ctx.to_device(x, torch.uint8), 16, 16, "INTER_NEAREST")
+    for bad in ("INTER_NEAREST_EXACT", 6, 7, -1, "INTER_LINEAR_EXACT", True):     # not restated / not a cv2.resize code (cv2.error in the reference)
+        with pytest.raises(ValueError):
+            ctx.resize(ctx.to_device(x, torch.uint8), 16, 16, bad)
+
+
+@pytest.mark.parametrize("shape,out", [((1, 48, 40, 3), (24, 20)),      # 2 x 2 cells, 3 channels: (sum + 2) >> 2
+                                       ((2, 48, 40, 2), (24, 20)),      # 2 x 2 cells, 2 channels: the rounded float product
+                                       ((1, 36, 45, 3), (12, 9)),       # 3 x 5 cells
+                                       ((1, 60, 32, 1), (15, 32)),      # 4 x 1 cells (one axis unchanged)
+                                       ((2, 37, 50, 3), (11, 17)),      # no whole-number factor: float taps
+                                       ((1, 64, 64, 4), (5, 9)),
+                                       ((1, 30, 21, 3), (10, 20))])     # one axis whole-number, one not: float taps
+def test_resize_area_shrinking_u8_bit_exact(ctx, shape, out):
+    """uint8 INTER_AREA shrinking (classic_algorithms.py:15-17 on the notebook's uint8 images): resizeAreaFast_ for whole-number factors,
+    resizeArea_<uchar, float> otherwise -- to the last bit of the CPU restatement, values at both ends of the range included."""
+    rng = np.random.default_rng(shape[1] * 7 + out[0])
+    x = rng.integers(0, 256, shape, dtype=np.uint8)
+    x[:, : shape[1] // 3] = 255
+    x[:, -(shape[1] // 4):, : shape[2] // 2] = 0
+    got = ctx.resize(ctx.to_device(x, torch.uint8), out[0], out[1], "INTER_AREA").cpu().numpy()
+    for b in range(shape[0]):
+        ref = O.cv_resize_u8(x[b], out[0], out[1], O.INTER_AREA)
+        assert np.array_equal(got[b], ref), (shape, out, int(np.abs(got[b].astype(int) - ref.astype(int)).max()))
+    if shape[1] == 2 * out[0] and shape[2] == 2 * out[1]:                 # cv2.resize turns bilinear halving into this very box mean
+        lin = ctx.resize(ctx.to_device(x, torch.uint8), out[0], out[1], "INTER_LINEAR").cpu().numpy()
+        assert np.array_equal(lin, got)
+        assert np.array_equal(lin[0], O.cv_resize_u8(x[0], out[0], out[1], O.INTER_LINEAR))
+
+
+@pytest.mark.parametrize("shape,out", [((2, 24, 20, 3), (48, 40)), ((1, 17, 9, 1), (40, 37)), ((1, 37, 50, 3), (11, 17)), ((1, 8, 8, 3), (8, 8))])
+def test_resize_nearest(ctx, shape, out):
+    """INTER_NEAREST = 0: a code interpolation_map.pkl may hold as an integer (loading_methods.py:146-147 hands it to cv2.resize as it is)."""
+    rng = np.random.default_rng(out[1])
+    xf = rng.uniform(0, 1, shape).astype(np.float32)
+    xu = rng.integers(0, 256, shape, dtype=np.uint8)
+    for name in ("INTER_NEAREST", 0):
+        assert np.array_equal(ctx.resize(ctx.to_device(xf), out[0], out[1], name).cpu().numpy(), O.cv_resize(xf, out[0], out[1], O.INTER_NEAREST))
+        got = ctx.resize(ctx.to_device(xu, torch.uint8), out[0], out[1], name).cpu().numpy()
+        assert np.array_equal(got, np.stack([O.cv_resize_u8(xu[b], out[0], out[1], O.INTER_NEAREST) for b in range(shape[0])]))
+    assert np.array_equal(ctx.resize(ctx.to_device(xf), out[0], out[1], "INTER_LINEAR_EXACT").cpu().numpy(),
+                          ctx.resize(ctx.to_device(xf), out[0], out[1], "INTER_LINEAR").cpu().numpy())      # float images: OpenCV falls back to INTER_LINEAR

@@ -122,3 +122,37 @@ def test_edsr_and_esrgan_graph_shapes():
     w = init_weights(M.esrgan_g_layers(4, 8, 1))
     y = M.esrgan_g_forward(np.zeros((1, 6, 5, 3), np.float32), w, 4, 1)
     assert y.shape == (1, 24, 20, 3) and np.abs(y).max() <= 1
+
+
+def test_u8_area_shrink_and_nearest_against_naive_loops():
+    """Round 4: uint8 INTER_AREA shrinking and INTER_NEAREST (cv2.resize; classic_algorithms.py:15-17, loading_methods.py:146-147) against an
+    independent per-pixel derivation: exact rational cell means for whole-number factors, float32 tap loops otherwise."""
+    from fractions import Fraction
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, 256, (12, 18, 3), dtype=np.uint8)
+    # whole-number factors: 3 x 3 cells -> round-half-even of sum * float32(1/9); 2 x 2 cells -> (sum + 2) >> 2
+    got = O.cv_resize_u8(a, 4, 6, O.INTER_AREA)
+    for y in range(4):
+        for x in range(6):
+            for c in range(3):
+                s = int(a[3 * y:3 * y + 3, 3 * x:3 * x + 3, c].astype(np.int64).sum())
+                assert abs(int(got[y, x, c]) - float(Fraction(s, 9))) <= 0.5 + 1e-4
+    got = O.cv_resize_u8(a, 6, 9, O.INTER_AREA)
+    s = a.astype(np.int64).reshape(6, 2, 9, 2, 3).sum(axis=(1, 3))
+    assert np.array_equal(got, (s + 2) // 4)
+    assert np.array_equal(O.cv_resize_u8(a, 6, 9, O.INTER_LINEAR), got)            # bilinear halving is the box mean
+    two = a[:, :, :2].copy()                                                        # two channels: the float product, ties to even
+    got2 = O.cv_resize_u8(two, 6, 9, O.INTER_AREA)
+    s2 = two.astype(np.int64).reshape(6, 2, 9, 2, 2).sum(axis=(1, 3))
+    assert np.array_equal(got2, np.rint(s2 * 0.25).astype(np.uint8)) and np.any(got2 != (s2 + 2) // 4)
+    # no whole-number factor: within half a grey level of the exact area integral, and monotone under a constant image
+    got = O.cv_resize_u8(a, 5, 7, O.INTER_AREA)
+    f = O.cv_resize(a.astype(np.float32), 5, 7, O.INTER_AREA)
+    assert np.array_equal(got, np.clip(np.rint(f), 0, 255).astype(np.uint8))
+    assert np.array_equal(O.cv_resize_u8(np.full((12, 18, 3), 200, np.uint8), 5, 7, O.INTER_AREA), np.full((5, 7, 3), 200, np.uint8))
+    # nearest: floor(d * src / dst), clamped
+    n = O.cv_resize_u8(a, 24, 27, O.INTER_NEAREST)
+    for y in (0, 5, 23):
+        for x in (0, 13, 26):
+            assert np.array_equal(n[y, x], a[min(int(np.floor(y * (1 / (24 / 12)))), 11), min(int(np.floor(x * (1 / (27 / 18)))), 17)])
+    assert np.array_equal(O.cv_resize(a.astype(np.float32), 5, 7, O.INTER_NEAREST), O.cv_resize_u8(a, 5, 7, O.INTER_NEAREST).astype(np.float32))

@@ -223,8 +223,8 @@ def test_classic_resizers_and_srcnn_mode_loader_with_interpolation_map(ctx, tmp_
     root = str(tmp_path)
     os.makedirs(os.path.join(root, "hr"))
     os.makedirs(os.path.join(root, "lr"))
-    names = ["a.png", "b.png", "c.png", "d.png", "e.png"]
-    methods = {"a.png": "INTER_LINEAR", "b.png": "INTER_AREA", "c.png": 4, "d.png": "INTER_SOMETHING_ELSE"}     # e.png: not in the map -> cubic
+    names = ["a.png", "b.png", "c.png", "d.png", "e.png", "f.png"]
+    methods = {"a.png": "INTER_LINEAR", "b.png": "INTER_AREA", "c.png": 4, "d.png": "INTER_SOMETHING_ELSE", "f.png": 0}     # e.png: not in the map -> cubic; 0 = cv2.INTER_NEAREST, as an integer straight to the resize
     imgs = {}
     for n in names:
         h = rng.integers(0, 256, (40, 36, 3), dtype=np.uint8)
@@ -237,7 +237,7 @@ def test_classic_resizers_and_srcnn_mode_loader_with_interpolation_map(ctx, tmp_
         pickle.dump(methods, f)
     X, Y, hh, ww = LM.load_dataset_as_patches(os.path.join(root, "hr"), os.path.join(root, "lr"), mode="srcnn", patch_size=12, stride=6,
                                               interpolation_map_path=mp)
-    codes = {"a.png": O.INTER_LINEAR, "b.png": O.INTER_AREA, "c.png": O.INTER_LANCZOS4, "d.png": O.INTER_CUBIC, "e.png": O.INTER_CUBIC}
+    codes = {"a.png": O.INTER_LINEAR, "b.png": O.INTER_AREA, "c.png": O.INTER_LANCZOS4, "d.png": O.INTER_CUBIC, "e.png": O.INTER_CUBIC, "f.png": O.INTER_NEAREST}
     Xr, Yr = [], []
     for n in names:
         h, l = imgs[n]

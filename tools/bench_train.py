@@ -54,6 +54,8 @@ D.allreduce_max(t)
 if rank == 0:
     wall = float(t.item())
     row.update({"n_gpus": world, "ms_per_step": 1e3 * wall / steps, "patches_per_s": batch * world * steps / wall,
-                "allreduce_ms_per_step": (sum(allreduce_ms) / (steps + 1)) if allreduce_ms else None})
+                # the warm-up step's calls (RCCL communicator set-up among them) are reported on their own, not folded into the per-step figure
+                "allreduce_ms_per_step": (sum(allreduce_ms[len(allreduce_ms) // (steps + 1):]) / steps) if allreduce_ms else None,
+                "allreduce_ms_warmup_step": sum(allreduce_ms[:len(allreduce_ms) // (steps + 1)]) if allreduce_ms else None})
     print(json.dumps(row))
 D.shutdown()

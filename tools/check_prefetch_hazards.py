@@ -106,7 +106,8 @@ def check_kernel(name, k):
             no, op, args = ins[pc]
             if op.startswith("scratch_"):
                 problems.append(f"{name}: line {no}: scratch access `{op} {args}`")
-            pending = set().union(*q) if q else set()
+            pending = set().union(*(d for d, _ in q)) if q else set()
+            pending_other = set().union(*(d for d, io in q if not io)) if q else set()     # destinations of in-flight loads that are NOT global_/buffer_ loads
             if op == "s_waitcnt":
                 m = VMCNT.search(args)
                 if m:
@@ -124,10 +125,16 @@ def check_kernel(name, k):
                 # reads return in issue order (that order is what vmcnt counts), so the younger load's data lands last.  hipcc produces the pattern
                 # when the earlier value is dead on some path (round 3: the epilogue's skip loads of a row whose stores are predicated off).  What
                 # must not happen is an instruction READING such a register, or using it as an address, before the wait.
-                bad = used & pending
+                # That in-order argument holds among global_* / buffer_* loads only (one return queue, the one vmcnt counts): a flat_* load may
+                # be served by the LDS path and return out of order with respect to them, so for any other pairing the destination overlap is
+                # still reported.
+                in_order = op.startswith(("global_load", "buffer_load"))
+                bad = (used | (set() if in_order else dest)) & pending
+                if in_order and dest & pending_other:
+                    bad |= dest & pending_other
                 if bad:
                     problems.append(f"{name}: line {no}: `{op} {args}` touches v{sorted(bad)} while a load into it may be in flight")
-                q = (q + (frozenset(dest),))[-64:]
+                q = (q + ((frozenset(dest), in_order),))[-64:]
             else:
                 bad = regs_of(args) & pending
                 if bad:

@@ -26,7 +26,7 @@ struct P {
 };
 
 template <int MODE>
-__global__ void __launch_bounds__((MODE == 2 || MODE == 4) ? 768 : 512) k(P p) {
+__global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 512) k(P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,9 +82,13 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4) ? 768 : 512) k(P p) {
         for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(base + j * 1024);
 #pragma unroll
         for (int j = 0; j < 3; ++j) { x[0][j] = *reinterpret_cast<const bf16x8*>(base + 24576 + j * 1024); x[1][j] = *reinterpret_cast<const bf16x8*>(base + 28672 + j * 1024); }
+        // mode 5: two barriers per granule, waves 4-7 (the SIMD partners of waves 0-3) run half a granule behind: one extra barrier up front,
+        // one more at the end (MI355X_MICROARCH.md "try a stagger"): a wave's barrier wait and post-barrier ramp meet its partner's MFMAs
+        if (MODE == 5 && wave >= 4) __builtin_amdgcn_s_barrier();
         for (int it = 0; it < p.iters; ++it) {
 #pragma unroll
             for (int s = 0; s < 18; ++s) {
+                if (MODE == 5 && s == 9) __builtin_amdgcn_s_barrier();      // mid-granule: the partner group's boundary; this wave's reads stay in flight
                 if (MODE >= 1) {
                     // one weight fragment per stage (3 stages ahead), three pixel fragments every 4-5 stages: 18 + 12 reads per 54 MFMAs
                     w[(s + 3) & 3] = *reinterpret_cast<const bf16x8*>(base + (((s + it) & 31) << 10));
@@ -98,7 +102,7 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4) ? 768 : 512) k(P p) {
                     acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[s & 3], x[((s + 2) >> 2) & 1][cg], acc[s], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (MODE == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+            if (MODE == 2 || MODE == 5) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
             if (MODE == 4) {
                 // done: this wave has finished reading granule `it`; then wait until the loaders have published granule it + 1
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -107,11 +111,12 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4) ? 768 : 512) k(P p) {
                 while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4 * (it + 2) && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
             }
         }
+        if (MODE == 5 && wave < 4) __builtin_amdgcn_s_barrier();
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 18; ++j) sum += acc[j][0] + acc[j][3];
         if (sum == 12345.678f) p.sink[0] = sum;
-    } else if (MODE == 2 || MODE == 3 || MODE == 4) {
+    } else if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5) {
         // loaders: per granule 29 pieces over 4 waves (7-8 each): ~11 from a private HBM stream (nt), ~18 from the shared random buffer (L2)
         const int lw = wave - (MODE == 3 ? 4 : 8);
         (void)flags;
@@ -137,8 +142,10 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4) ? 768 : 512) k(P p) {
                 while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 8 * (it - 1) && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
             } else {
                 __builtin_amdgcn_s_barrier();
+                if (MODE == 5) __builtin_amdgcn_s_barrier();
             }
         }
+        if (MODE == 5) __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -169,12 +176,13 @@ int main() {
     const int lds = 150 * 1024;
     const char* names[] = {"bare MFMA, operands in registers", "MFMA + LDS operand reads (30 ds_read_b128 per 54 MFMAs)", "MFMA + LDS reads + 29 KiB of LDS-DMA per granule + one barrier per granule",
                            "4 compute waves (one per SIMD) x two rows: 33 reads per 108 MFMAs, + LDS-DMA + barrier per granule",
-                           "mode 2 with the per-granule barrier replaced by a ready / done handshake through LDS counters"};
-    for (int mode = 0; mode < 5; ++mode) {
-        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : mode == 3 ? k<3> : k<4>;
+                           "mode 2 with the per-granule barrier replaced by a ready / done handshake through LDS counters",
+                           "mode 2 with two barriers per granule and waves 4-7 half a granule behind their SIMD partners (stagger)"};
+    for (int mode = 0; mode < 6; ++mode) {
+        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : mode == 3 ? k<3> : mode == 4 ? k<4> : k<5>;
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         P p{rnd, hbm, per_wg, stamps, sink, 20000};
-        const int threads = (mode == 2 || mode == 4) ? 768 : 512;      // mode 3: 4 compute + 4 loader waves
+        const int threads = (mode == 2 || mode == 4 || mode == 5) ? 768 : 512;      // mode 3: 4 compute + 4 loader waves
         float ms = 0.f, total = 0.f;
         int n = 0;
         while (total < 2500.f && n < 400) {             // ~2.5 s of back-to-back launches, the last one is the measurement
