@@ -273,7 +273,7 @@ def main():
                     help="round 1's weights: glorot without conditioning the attention logits (sr355.weights.condition_attention)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the other BASELINE rows (cfg3 training step, cfg4 streaming) that the N = 1 line carries beside the headline")
-    ap.add_argument("--fused", type=int, default=255,
+    ap.add_argument("--fused", type=int, default=511,
                     help="dense-block conv pairs run as one fused kernel: bit 0 conv4+conv5, bit 1 conv2+conv3, bit 2 final_conv2 inside final_conv1, bit 3 attention projections inside the producing conv (0 = layer by layer, for A/B runs)")
     args = ap.parse_args()
     if args.chunk <= 0:
@@ -431,7 +431,7 @@ def main():
                                    "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
                        "tiles_this_rank": n_mine, "global_batch": global_tiles, "patches_per_forward": min(args.chunk, 441 * max(n_mine, 1)),
                        "tiles_per_call": args.tiles_per_call, "fused_dense_pairs_mask": args.fused,
-                       "fused_mask_bits": "1 conv4+conv5, 2 conv2+conv3, 4 final_conv2 inside final_conv1, 8 attention projections inside the producing conv, 16 packed small-image batches (classifier), 32 conv1 of a dense block on the streaming kernel, 64 max-pool inside the conv in front of it (classifier), 128 64-input-channel 3x3 convs on the persistent kernel",
+                       "fused_mask_bits": "1 conv4+conv5, 2 conv2+conv3, 4 final_conv2 inside final_conv1, 8 attention projections inside the producing conv, 16 packed small-image batches (classifier), 32 conv1 of a dense block on the streaming kernel, 64 max-pool inside the conv in front of it (classifier), 128 64-input-channel 3x3 convs on the persistent kernel, 256 SRCNN's 1x1 conv inside the 9x9 head's epilogue",
                        "distinct_tiles": 4, "tile_of_batch_index": "batch tile t is synthetic tile t % 4 (4 distinct 512x512 tiles, each 4 times; nothing is cached between tiles)",
                        "world_size_env": world, "world_size_process_group": group_world, "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
                        "parallelism": f"dp{group_world} (tile shards, metric all-reduce only)"},

@@ -105,7 +105,8 @@ int64_t sr_debug_stamp_bytes_needed(int which, int64_t workgroups);
  * tall image for the 3x3 kernel, whose 12 x 16 output tiles a single such image would fill to 19 %; bit 5 = conv1 of a dense block (64 -> 32 channels, the block's one
  * HBM-bound conv) on a streaming line-buffer kernel with its weights resident in LDS; bit 6 = a MaxPooling2D computed in the epilogue of the conv in front of it
  * (every VGG16 block ends conv -> pool: the full-resolution tensor is never stored); bit 7 = 3x3 convs from 64 input channels (the generator's
- * up-sampling convs, EDSR's body) on a persistent kernel that keeps a 64-cout tile's weights in LDS; default 255.
+ * up-sampling convs, EDSR's body) on a persistent kernel that keeps a 64-cout tile's weights in LDS; bit 8 = SRCNN's 1x1 conv (conv2d_1, 96 -> 32, ReLU:
+ * SRCNN_model.py:51) computed from the accumulators in the epilogue of the 9x9 head, whose 96-channel fp32 output is then never stored; default 511.
  * mask 0 = layer by layer (the A/B switch of the parity tests and of tools/ benchmarks).  max_workgroups > 0 caps the persistent grid (tests: several images per workgroup
  * at small batches); 0 = one workgroup per CU. */
 int  sr_debug_set_fused(sr_ctx* ctx, int mask, int max_workgroups);

@@ -119,6 +119,7 @@ struct Op {
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
     int chain = -1, chain_pos = 0;                  // conv: member (first / second) of m->chains[chain]
     int rgbtail = -1;                               // conv: first op of m->rgbtails[rgbtail] (the next op is the conv folded into this one's epilogue)
+    int pw2 = -1;                                   // conv: the next op is the 1x1 conv m->pw2s[pw2], which this fp32 thin conv's epilogue can compute from its accumulators
     int proj = -1;                                  // conv: the next op is the 1x1 projection m->projs[proj], which this conv's epilogue can compute
 };
 struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; int cells = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs); cells: small images may be packed in a CellGrid (common.h)
@@ -130,6 +131,7 @@ struct ChainSpec { int conv_a = -1, conv_b = -1; int tail = 0; ChainWeights w; }
 struct RgbTailSpec { int conv_b = -1; RgbTailWeights w; };
 // the f / g / h projections of a SelfAttention layer, computed in the epilogue of the conv that produces the layer's input (conv_rows.hip)
 struct ProjSpec { int conv = -1; ProjWeights w; };
+struct Pw2Spec { int conv = -1; int act = 0; Pw2Weights w; };
 
 }  // namespace
 
@@ -143,6 +145,7 @@ struct sr_model {
     std::vector<ChainSpec> chains;
     std::vector<RgbTailSpec> rgbtails;
     std::vector<ProjSpec> projs;
+    std::vector<Pw2Spec> pw2s;
     std::vector<BufSpec> bufs;
     std::vector<void*> bufp;
     std::vector<float*> dense_dev;    // per param index (dense kernels / biases on device), else nullptr
@@ -220,6 +223,13 @@ int build_srcnn(sr_model* m) {
     Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
     b.conv("conv2d", 9, C, 96, {x0, 0}, {c1, 0}, SR_ACT_RELU);
     b.conv("conv2d_1", 1, 96, 32, {c1, 0}, {c2, 0}, SR_ACT_RELU);
+    if (m->T == SR_DTYPE_F32 && C == 3) {
+        // the 96-channel intermediate must never reach HBM -- the head's epilogue computes this 1x1 from its accumulators
+        // (conv.hip, conv_thin_kernel PW2); sr_forward decides per call (a tap on conv2d, or sr_debug_set_fused without bit 8, runs the two convs)
+        Pw2Spec ps; ps.conv = m->ops.back().conv; ps.act = SR_ACT_RELU;
+        m->pw2s.push_back(ps);
+        m->ops[m->ops.size() - 2].pw2 = (int)m->pw2s.size() - 1;
+    }
     b.conv("conv2d_2", 5, 32, C, {c2, 0}, {-2, 0});
     return SR_OK;
 }
@@ -686,6 +696,7 @@ void sr_model_destroy(sr_model* m) {
     for (auto& ch : m->chains) chain_free_weights(m->ctx, &ch.w);
     for (auto& rt : m->rgbtails) rgbtail_free_weights(m->ctx, &rt.w);
     for (auto& pj : m->projs) proj_free_weights(m->ctx, &pj.w);
+    for (auto& pw : m->pw2s) pw2_free_weights(m->ctx, &pw.w);
     for (auto& p : m->dense_dev) if (p) m->ctx->dfree(p);
     delete m;
 }
@@ -822,6 +833,14 @@ int sr_model_finalize(sr_model* m) {
         int rc = proj_pack_weights(ctx, k.data(), bias.data(), c1.Cout, &pj.w);
         if (rc) return rc;
     }
+    for (auto& pw : m->pw2s) {
+        pw2_free_weights(ctx, &pw.w);
+        const ConvSpec& c1 = m->convs[pw.conv];
+        std::vector<float> k, bias;
+        gather(c1, k, bias);
+        int rc = pw2_pack_weights(ctx, k.data(), bias.data(), c1.Cin, c1.Cout, pw.act, &pw.w);
+        if (rc) return rc;
+    }
     for (auto& op : m->ops) {
         if (op.kind != OP_DENSE) continue;
         for (int pi : {op.dw, op.db}) {
@@ -926,6 +945,17 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                     rc = rgbtail_finish_launch(ctx, rt.w, ep1.f2_part, B, h, w, ob.act, ob.alpha, ob.clip, y, m->out_C, 0, io_dtype == SR_DTYPE_F32, st);
                     if (rc) return rc;
                     ++oi;                                             // the second conv has run
+                    break;
+                }
+                if (op.pw2 >= 0 && (ctx->chain_mask & 256) && m->taps.count((int)oi) == 0 && cs.w.thin && !cs.w.few && cs.w.dtype == SR_DTYPE_F32 && op.skip1.buf < 0 &&
+                    op.skip2.buf < 0 && op.d2s == 1 && !op.clip) {
+                    // conv2d (9x9, ReLU) + conv2d_1 (1x1, ReLU) as one kernel: only the 32-channel tensor is stored
+                    const Op& ob = m->ops[oi + 1];
+                    ConvEpilogue ep2;
+                    ep2.act = op.act; ep2.alpha = op.alpha; ep2.pw2 = &m->pw2s[op.pw2].w;
+                    rc = conv_launch(ctx, cs.w, xin, B, h, w, TensorView{m->bufp[ob.out.buf], m->bufs[ob.out.buf].Cbuf, ob.out.coff, m->bufs[ob.out.buf].blk}, ep2, st);
+                    if (rc) return rc;
+                    ++oi;                                             // the 1x1 has run
                     break;
                 }
                 ConvEpilogue ep;

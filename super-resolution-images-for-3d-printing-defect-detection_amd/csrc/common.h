@@ -57,7 +57,7 @@ struct sr_ctx {
                                   // synchronously in sr_init, so that no launch on any stream can see it before it is zero
     int num_cus = 0;
     int cu_count();               // compute units of the device (queried once)
-    int chain_mask = 255;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid, bit 5: conv1 of a dense block on the streaming kernel, bit 6: a 2x2 max-pool inside the conv in front of it, bit 7: 64-input-channel 3x3 convs on the persistent kernel of conv_stream.hip (sr_debug_set_fused; default all)
+    int chain_mask = 511;          // bit 0: fuse conv4+conv5 of a dense block, bit 1: fuse conv2+conv3, bit 2: fold the generator's RGB conv into final_conv1, bit 3: SelfAttention's f / g / h projections in the producing conv's epilogue bit 4: batches of small images (VGG16 block 5) packed in a CellGrid, bit 5: conv1 of a dense block on the streaming kernel, bit 6: a 2x2 max-pool inside the conv in front of it, bit 7: 64-input-channel 3x3 convs on the persistent kernel of conv_stream.hip, bit 8: SRCNN's 1x1 conv inside the 9x9 head's epilogue (sr_debug_set_fused; default all)
     int chain_max_wgs = 0;        // test hook: cap the persistent grid so that small batches still give several images per workgroup
     int64_t alloc_cap = 0;        // test hook (sr_debug_set_alloc_cap): dalloc fails once cur_bytes would exceed it; 0 = none
 
@@ -129,6 +129,14 @@ struct ProjWeights {
     int nblk = 0;
 };
 
+// Fused 1x1 conv behind an fp32 thin conv (conv.hip, conv_thin_kernel): SRCNN's conv2d_1 (96 -> 32, ReLU) computed in conv2d's epilogue from the
+// accumulators, so that the 96-channel fp32 tensor never reaches HBM (SRCNN_model.py:48-53)
+struct Pw2Weights {
+    float* a = nullptr;       // [NT = cin / 32][16][64 lanes] fp32: the A operand of the (n, i) step of the 32x32x2 fp32 MFMA chain, 0 beyond cout2
+    float* bias = nullptr;    // [32] fp32, zero padded
+    int cin = 0, cout = 0, act = 0;
+};
+
 // Packed layout of a batch of SMALL images (api.hip: VGG16 block 5).  A 6 x 6 image uses 19 % of the 12 x 16 output tile the 64-cout kernel
 // issues MFMAs for.  Image b instead sits in cell (b / gx, b % gx) of a grid of ch x cw = (h + 1) x (w + 1) cells whose last row / column is a
 // ZERO separator (the bottom / right padding of one image and the top / left padding of the next), and the whole batch is ONE image of Hv x Wv
@@ -146,6 +154,7 @@ struct ConvEpilogue {
     int cell_h = 0, cell_w = 0;           // conv_rows: do not store output rows y with y % cell_h == cell_h - 1 / columns x with x % cell_w == cell_w - 1 (CellGrid separators)
     const ProjWeights* pj = nullptr;      // conv_rows, 64 couts per output pixel, NHWC output: also write the 1x1 projection of the output to pj_out
     TensorView pj_out;                    // NHWC bf16 view at the conv's output resolution, >= 16 * nblk channels from coff
+    const Pw2Weights* pw2 = nullptr;      // fp32 thin conv owning all its couts in one workgroup, no skips: store act2(W2 . act(conv) + b2) (<= 32 channels) instead of the conv's own output
     const RgbTailWeights* f2 = nullptr;   // conv_rows, 64 couts, no skips: do not store this conv's output, write the following conv's partial sums to f2_part
     float* f2_part = nullptr;             // rgbtail_partial_bytes(B, H, W) bytes
     int act = SR_ACT_LINEAR;
@@ -174,6 +183,8 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
 
 // fused 1x1 projection: pack the HWIO kernel [1,1,64,16 * nblk] (+ bias) of the 1x1 conv that follows a 64-channel conv_rows conv
 int proj_pack_weights(sr_ctx* ctx, const float* w_hwio, const float* bias, int cout, ProjWeights* out);
+int pw2_pack_weights(sr_ctx* ctx, const float* w_hwio, const float* bias, int cin, int cout, int act, Pw2Weights* out);
+void pw2_free_weights(sr_ctx* ctx, Pw2Weights* w);
 void proj_free_weights(sr_ctx* ctx, ProjWeights* w);
 // fused RGB tail: pack the second conv's HWIO kernel [3,3,64,c2] (+ bias), size of the partial-sum buffer, and the pass that adds the
 // partial sums of the tiles covering an output pixel, applies bias / activation / alpha / clip and stores NHWC (bf16, or fp32 with out_f32)

@@ -50,6 +50,14 @@ __device__ __forceinline__ f32x16 mma(f32x4 a, f32x4 b, f32x16 c) {
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
     return c;
 }
+// the first NV of a 16-byte slice's channels only: an RGB image padded to four fp32 channels carries a zero in the fourth (weights and
+// pixels alike), whose MFMA adds exactly 0 -- skipping it is the same sum with a quarter fewer matrix instructions (round 4)
+template <int NV> __device__ __forceinline__ f32x16 mma_nv(f32x4 a, f32x4 b, f32x16 c) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+template <int NV> __device__ __forceinline__ f32x16 mma_nv(bf16x8 a, bf16x8 b, f32x16 c) { return mma(a, b, c); }
 
 // Epilogue of the 32x32 kernels: lane (r,h) owns pixel r of each M-block and couts 8q+4h..+3.
 template <typename T, int NT, int MT>
@@ -175,7 +183,12 @@ __global__ void __launch_bounds__(256) conv_wide_kernel(ConvParams p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int THIN_GPS = 16;   // k-groups per weight stage
 
-template <typename T, int KS, int NT, int MT>
+// NV: fp32 only -- valid channels of the slice (3 for an RGB image: the padding channel's MFMA is skipped).
+// PW2: fp32 only -- a 1x1 conv to <= 32 channels (p.pw2w, Pw2Weights) is computed from the accumulators in the epilogue and stored INSTEAD of this conv's
+// output: the workgroup owns all NT * 32 couts of its pixels (gridDim.y == 1).  In the 32x32 accumulator layout lane (r, h) holds, for pixel r of an M-block,
+// couts 32 n + 8 (i / 4) + 4 h + (i % 4) in element i of block n -- which IS the B operand of a 32x32x2 fp32 MFMA whose two k values are the couts lane
+// halves 0 and 1 hold in the same element: the second conv is NT * 16 MFMAs per M-block on the activated accumulators, no cross-lane movement.
+template <typename T, int KS, int NT, int MT, int NV = 4, bool PW2 = false>
 __global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
     typedef typename TT<T>::frag frag;
     constexpr int TH = 8 * MT, TW = 16;
@@ -238,10 +251,34 @@ __global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = mma(wf[n], xf[m], acc[m][n]);
+                for (int n = 0; n < NT; ++n) acc[m][n] = mma_nv<NV>(wf[n], xf[m], acc[m][n]);
         }
     }
-    conv_epilogue<T, NT, MT>(p, acc, b, y0, x0, ct, wave, r, h);
+    if constexpr (PW2 && std::is_same<T, float>::value) {
+        __syncthreads();                                           // every wave is done with the weight stage: the 1x1's A operands take its place
+        float* l2 = reinterpret_cast<float*>(lw);
+        for (int u = tid; u < NT * 16 * 64; u += 256) l2[u] = p.pw2w[u];
+        __syncthreads();
+        ConvParams q = p;
+        q.bias = p.pw2bias; q.Cout = p.pw2_cout; q.act = p.pw2_act; q.alpha = 1.f;
+        f32x16 acc2[MT][1];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[m][0][e] = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 32 * n + 8 * (i >> 2) + 4 * h + (i & 3);
+                    const float v = act_apply(acc[m][n][i] + p.bias[c], p.act) * p.alpha;
+                    acc2[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(l2[(n * 16 + i) * 64 + lane], v, acc2[m][0], 0, 0, 0);
+                }
+        }
+        conv_epilogue<T, 1, MT>(q, acc2, b, y0, x0, 0, wave, r, h);
+    } else {
+        conv_epilogue<T, NT, MT>(p, acc, b, y0, x0, ct, wave, r, h);
+    }
 }
 
 constexpr int MT_DEFAULT = 3;   // 24 x 16 pixel tiles: 48/96/192-pixel patches tile exactly
@@ -274,16 +311,17 @@ int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     return launch_wide_mt<T, KS, KGPT, NT, MT_DEFAULT>(ctx, p0, nct, st);
 }
 
-template <typename T, int KS, int NT>
+template <typename T, int KS, int NT, int NV = 4, bool PW2 = false>
 int launch_thin(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     constexpr int MT = MT_DEFAULT;
     constexpr int PH = 8 * MT + KS - 1, PW = 16 + KS - 1;
     constexpr int KGT = (KS * KS + 1) / 2;
     constexpr int lds = PH * PW * 16 + (KGT < THIN_GPS ? KGT : THIN_GPS) * NT * 1024;
+    static_assert(!PW2 || (KGT < THIN_GPS ? KGT : THIN_GPS) * NT * 1024 >= NT * 16 * 64 * 4, "the fused 1x1's operands fit the weight stage");
     ConvParams p = p0;
     p.tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 8 * MT - 1) / (8 * MT);
-    auto kern = conv_thin_kernel<T, KS, NT, MT>;
+    auto kern = conv_thin_kernel<T, KS, NT, MT, NV, PW2>;
     if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
@@ -312,6 +350,12 @@ int dispatch_thin_nt(sr_ctx* ctx, const ConvParams& p, int NT, int nct, hipStrea
 
 template <typename T>
 int dispatch(sr_ctx* ctx, const ConvWeights& w, const ConvParams& p, int nct, hipStream_t st) {
+    if constexpr (std::is_same<T, float>::value) {
+        // SRCNN's head (SRCNN_model.py:50): 9x9 on an RGB image to 96 channels, optionally with the 1x1 that follows it in the epilogue
+        if (w.thin && w.KS == 9 && w.NT == 3 && nct == 1 && w.Cin == 3)
+            return p.pw2w ? launch_thin<T, 9, 3, 3, true>(ctx, p, nct, st) : launch_thin<T, 9, 3, 3, false>(ctx, p, nct, st);
+    }
+    if (p.pw2w) return ctx->fail(SR_ERR_INVALID, "conv: the fused 1x1 follows the fp32 9x9 RGB head only");
     if (w.thin) {
         switch (w.KS) {
             case 3: return dispatch_thin_nt<T, 3>(ctx, p, w.NT, nct, st);
@@ -626,6 +670,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.f2w = nullptr; p.f2part = nullptr; p.f2c = 0;
     p.pjw = nullptr; p.pjbias = nullptr; p.pjout = nullptr; p.pj_cs = 0; p.pj_coff = 0; p.pj_rs = 0; p.pj_nblk = 0;
     p.cell_h = ep.cell_h; p.cell_w = ep.cell_w;
+    p.pw2w = nullptr; p.pw2bias = nullptr; p.pw2_cout = 0; p.pw2_act = 0;
     p.plout = nullptr; p.pl_cs = 0; p.pl_coff = 0; p.pl_gx = p.pl_ch = p.pl_cw = p.pl_Wv = 0;
     const int osz = p.out_f32 ? 4 : esz;
     bool vec = (y_cs % 4 == 0) && (y_coff % 4 == 0) && ((uintptr_t)y % (4 * osz) == 0) && (p.Cd % 4 == 0);
@@ -660,6 +705,13 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         p.skip_lds = 0; p.skip_scale = 0.f;                       // the projection epilogue adds skip 1 itself
         p.pjout = static_cast<char*>(const_cast<void*>(ep.pj_out.p)); p.pj_cs = ep.pj_out.cs; p.pj_coff = ep.pj_out.coff; p.pj_rs = (int)(W * r * ep.pj_out.cs);
     }
+    if (ep.pw2) {
+        if (!(w.dtype == SR_DTYPE_F32 && w.thin && !w.few && w.CoutP == 32 * w.NT && ep.pw2->a && ep.pw2->cin == w.Cout && ep.pw2->cout >= 1 && ep.pw2->cout <= 32 && r == 1 &&
+              !p.s1 && !p.s2 && !ep.clip01 && !ep.pj && !ep.f2 && !ep.pool_out.p && !yv.blk && yv.cs - yv.coff >= ep.pw2->cout))
+            return ctx->fail(SR_ERR_INVALID, "conv: the fused 1x1 follows an fp32 thin conv that owns all its couts in one workgroup, without skips");
+        p.pw2w = ep.pw2->a; p.pw2bias = ep.pw2->bias; p.pw2_cout = ep.pw2->cout; p.pw2_act = ep.pw2->act;
+        p.Cd = ep.pw2->cout;                                       // what is stored has pw2_cout channels: the vector-store test below is about them
+    }
     if (ep.f2) {
         if (!(w.rows && w.NT == 4 && w.Cout == 64 && w.CoutP == 64 && r == 1 && !p.s1 && !p.s2 && !ep.clip01 && ep.act != SR_ACT_TANH && ep.f2->a && ep.f2_part))
             return ctx->fail(SR_ERR_INVALID, "conv: the fused RGB tail follows a bf16 3x3 conv to 64 channels without skips");
@@ -679,6 +731,10 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         const double px = (double)B * H * W;
         rec = ctx->prof_open("conv_rows_proj<bf16,k3,nt4+1x1>", 2.0 * px * (9.0 * w.Cin * w.Cout + (double)w.Cout * 16 * ep.pj->nblk),
                              px * ((double)w.Cin * esz + (double)w.Cout * osz + (p.s1 ? (double)w.Cout * esz : 0.0) + (double)r * r * 16 * ep.pj->nblk * esz), st);
+    } else if (ctx->prof && ep.pw2) {
+        const double px = (double)B * H * W;
+        rec = ctx->prof_open("conv_thin_pw2<f32,k9,3->96->32>", 2.0 * px * ((double)w.KS * w.KS * w.Cin * w.Cout + (double)w.Cout * ep.pw2->cout),
+                             px * ((double)w.CinP * esz + (double)ep.pw2->cout * osz), st);
     } else if (ctx->prof) {
         char nm[96];
         snprintf(nm, sizeof nm, "conv_%s<%s,k%d,kg%d,nt%d>", w.few ? "few" : stream ? "stream" : w.rows ? "rows" : (w.pw ? "pw" : (w.thin ? "thin" : "wide")),
@@ -694,4 +750,36 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
                           : ((w.dtype == SR_DTYPE_BF16) ? dispatch<bf16_t>(ctx, w, p, nct, st) : dispatch<float>(ctx, w, p, nct, st));
     ctx->prof_close(rec, st);
     return rc;
+}
+
+// A operands of the fused 1x1 behind the fp32 thin kernel (conv_thin_kernel, PW2): step (n, i) of an M-block's MFMA chain multiplies, in lane l,
+// W2[cin = 32 n + 8 (i / 4) + 4 (l / 32) + (i % 4)][cout = l % 32] with the activation the same lane holds in element i of accumulator block n
+int pw2_pack_weights(sr_ctx* ctx, const float* w, const float* bias, int cin, int cout, int act, Pw2Weights* out) {
+    if (cin < 32 || cin % 32 != 0 || cin > 96 || cout < 1 || cout > 32) return ctx->fail(SR_ERR_INVALID, "fused 1x1: 32, 64 or 96 input and 1..32 output channels");
+    const int NT = cin / 32;
+    std::vector<float> host((size_t)NT * 16 * 64, 0.f);
+    for (int n = 0; n < NT; ++n)
+        for (int i = 0; i < 16; ++i)
+            for (int l = 0; l < 64; ++l) {
+                const int c = 32 * n + 8 * (i >> 2) + 4 * (l >> 5) + (i & 3), co = l & 31;
+                if (co < cout) host[((size_t)n * 16 + i) * 64 + l] = w[(size_t)c * cout + co];
+            }
+    Pw2Weights pw;
+    pw.cin = cin; pw.cout = cout; pw.act = act;
+    pw.a = static_cast<float*>(ctx->dalloc(host.size() * sizeof(float)));
+    if (!pw.a) return SR_ERR_OOM;
+    pw.bias = static_cast<float*>(ctx->dalloc(32 * sizeof(float)));
+    if (!pw.bias) { ctx->dfree(pw.a); return SR_ERR_OOM; }
+    float hb[32] = {0.f};
+    if (bias) for (int i = 0; i < cout; ++i) hb[i] = bias[i];
+    SR_HIP(ctx, hipMemcpy(pw.a, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    SR_HIP(ctx, hipMemcpy(pw.bias, hb, sizeof hb, hipMemcpyHostToDevice));
+    *out = pw;
+    return SR_OK;
+}
+
+void pw2_free_weights(sr_ctx* ctx, Pw2Weights* w) {
+    if (w->a) ctx->dfree(w->a);
+    if (w->bias) ctx->dfree(w->bias);
+    *w = Pw2Weights{};
 }

@@ -113,7 +113,9 @@ class Context:
         self.check(self.lib.sr_measure_clock(self.h, C.byref(mhz), self.stream()))
         return mhz.value
 
-    def set_fused(self, mask=255, max_workgroups=0):
+    FUSED_ALL = 511
+
+    def set_fused(self, mask=511, max_workgroups=0):
         """Which dense-block conv pairs run as one fused kernel (bit 0: conv4+conv5, bit 1: conv2+conv3) and whether the generator's RGB conv rides in
         final_conv1's epilogue (bit 2) and SelfAttention's f / g / h projections in the epilogue of the conv before it (bit 3); bit 4: batches of small images (VGG16 block 5) packed into one tall image with zero separators; bit 5: conv1 of a dense block on the streaming line-buffer kernel; bit 6: a 2x2 max-pool inside the epilogue of the conv in front of it; bit 7: 3x3 convs from 64 input channels on the persistent kernel with resident weights; 0 = layer by layer."""
         self.check(self.lib.sr_debug_set_fused(self.h, int(mask), int(max_workgroups)))

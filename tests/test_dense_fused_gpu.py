@@ -24,7 +24,7 @@ def rel_l2(a, b):
 @pytest.fixture()
 def fused_ctx(ctx):
     yield ctx
-    ctx.set_fused(255, 0)
+    ctx.set_fused(ctx.FUSED_ALL, 0)
 
 
 CASES = [

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def fused_ctx(ctx):
     yield ctx
-    ctx.set_fused(255, 0)
+    ctx.set_fused(ctx.FUSED_ALL, 0)
 
 
 def kernels_of(ctx, fn):

@@ -63,11 +63,11 @@ def device_trace(ctx, dtype, w, x, nb=NB, stages=STAGES):
         # so the two bf16 images differ by that one rounding of a 64-channel tensor: a flipped output rounding in a fraction of the pixels ...
         d = (y.float() - y2.float()).abs()
         assert float(d.max()) <= 2.0 ** -6 and float((d > 0).float().mean()) < 0.25, (float(d.max()), float((d > 0).float().mean()))
-        ctx.set_fused(255 & ~4, 0)                 # ... and are the same image when that pair runs as two kernels in both
+        ctx.set_fused(ctx.FUSED_ALL & ~4, 0)                 # ... and are the same image when that pair runs as two kernels in both
         try:
             assert torch.equal(y, m.forward(ctx.to_device(x, td)))
         finally:
-            ctx.set_fused(255, 0)
+            ctx.set_fused(ctx.FUSED_ALL, 0)
     return y.float().cpu().numpy(), {name: taps[dev].cpu().numpy() for name, dev in stages}
 
 

@@ -174,3 +174,65 @@ def test_cfg1_full_size_srcnn_fp32(ctx):
     assert np.max(np.abs(p - pr)) <= 1e-3 and np.max(np.abs(s - sr)) <= 1e-4
     alone = m.forward(up[7:8].contiguous())
     assert torch.equal(alone[0], y[7])
+
+
+# ---- SRCNN: conv2d_1 (1x1, 96 -> 32, ReLU) inside conv2d's epilogue (conv.hip conv_thin_kernel PW2; SRCNN_model.py:48-53) ----
+
+@pytest.mark.parametrize("shape", [(2, 24, 16, 3), (1, 33, 33, 3), (3, 50, 21, 3), (1, 7, 5, 3)])     # one tile exactly; ragged both ways; several tiles; smaller than a tile
+def test_srcnn_fused_1x1_matches_the_two_kernel_path_and_the_oracle(ctx, shape):
+    m = Model("srcnn", compute_dtype="f32", ctx=ctx)
+    w = init_weights(m.layer_shapes(), seed=1200 + shape[1])
+    m.set_weights(w)
+    x = np.random.default_rng(shape[2]).uniform(0, 1, shape).astype(np.float32)
+    xd = ctx.to_device(x)
+    try:
+        ctx.set_fused(ctx.FUSED_ALL & ~256, 0)
+        ctx.profile_begin()
+        y0, t0 = m.forward_with_taps(xd, ["conv2d_1"])
+        k0 = {r["kernel"] for r in ctx.profile_end()}
+        ctx.set_fused(ctx.FUSED_ALL, 0)
+        ctx.profile_begin()
+        y1, t1 = m.forward_with_taps(xd, ["conv2d_1"])
+        k1 = {r["kernel"] for r in ctx.profile_end()}
+    finally:
+        ctx.set_fused(ctx.FUSED_ALL, 0)
+    assert not any("pw2" in k for k in k0) and any(k.startswith("conv_thin_pw2") for k in k1), (k0, k1)      # the fused kernel is the one that ran
+    assert not any(k.startswith("conv_wide<f32,k1") for k in k1), k1                                         # ... and the 1x1 kernel did not
+    assert torch.equal(y1, m.forward(xd))
+    # a tap on the head needs its 96-channel output in memory: the pair then runs as two kernels
+    y2, t2 = m.forward_with_taps(xd, ["conv2d"])
+    assert torch.equal(y2, y0) and t2["conv2d"].shape == shape[:3] + (96,)
+    a1 = O.conv2d(x, *w["conv2d"], act="relu", dtype=np.float64)
+    a2 = O.conv2d(a1, *w["conv2d_1"], act="relu", dtype=np.float64)
+    ref = M.srcnn_forward(x, w, dtype=np.float64)
+    for got in (t0["conv2d_1"], t1["conv2d_1"]):
+        assert rel_l2(got.cpu().numpy(), a2) <= 2e-6
+    assert rel_l2(y1.cpu().numpy(), ref) <= 1e-5 and rel_l2(y0.cpu().numpy(), ref) <= 1e-5
+    assert np.abs(t1["conv2d_1"].cpu().numpy() - t0["conv2d_1"].cpu().numpy()).max() <= 1e-5 * max(1.0, float(np.abs(a2).max()))
+
+
+def test_srcnn_fused_1x1_exact_integers(ctx):
+    """Index arithmetic, exactly: small integer weights and pixels make every partial sum an exactly representable integer whatever the order
+    of the fp32 additions, so the fused kernel, the two-kernel path and the oracle must agree to the last bit -- every one of the 96 x 32
+    channel pairs of the 1x1 carries its own weight (a mis-ordered k index cannot cancel), ReLU cuts at both layers, ragged tiles, a batch."""
+    m = Model("srcnn", compute_dtype="f32", ctx=ctx)
+    rng = np.random.default_rng(77)
+    w = {"conv2d": (rng.integers(-2, 3, (9, 9, 3, 96)).astype(np.float32), rng.integers(-3, 4, 96).astype(np.float32)),
+         "conv2d_1": (rng.integers(-3, 4, (1, 1, 96, 32)).astype(np.float32), rng.integers(-5, 6, 32).astype(np.float32)),
+         "conv2d_2": (rng.integers(-1, 2, (5, 5, 32, 3)).astype(np.float32), np.zeros(3, np.float32))}
+    m.set_weights(w)
+    x = rng.integers(0, 3, (2, 29, 37, 3)).astype(np.float32)
+    xd = ctx.to_device(x)
+    try:
+        ctx.set_fused(ctx.FUSED_ALL & ~256, 0)
+        y0, t0 = m.forward_with_taps(xd, ["conv2d_1"])
+        ctx.set_fused(ctx.FUSED_ALL, 0)
+        y1, t1 = m.forward_with_taps(xd, ["conv2d_1"])
+    finally:
+        ctx.set_fused(ctx.FUSED_ALL, 0)
+    a2 = O.conv2d(O.conv2d(x, *w["conv2d"], act="relu", dtype=np.float64), *w["conv2d_1"], act="relu", dtype=np.float64)
+    assert a2.max() < 2 ** 24 and len(np.unique(a2)) > 1000 and (a2 == 0).mean() > 0.05          # exact in fp32, non-trivial, the second ReLU cuts
+    assert np.array_equal(t1["conv2d_1"].cpu().numpy(), a2) and np.array_equal(t0["conv2d_1"].cpu().numpy(), a2)
+    ref = M.srcnn_forward(x, w, dtype=np.float64)
+    assert np.abs(ref).max() < 2 ** 24
+    assert np.array_equal(y1.cpu().numpy(), ref) and np.array_equal(y0.cpu().numpy(), ref)
