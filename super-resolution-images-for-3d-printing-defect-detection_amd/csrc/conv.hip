@@ -188,7 +188,8 @@ constexpr int THIN_GPS = 16;   // k-groups per weight stage
 // output: the workgroup owns all NT * 32 couts of its pixels (gridDim.y == 1).  In the 32x32 accumulator layout lane (r, h) holds, for pixel r of an M-block,
 // couts 32 n + 8 (i / 4) + 4 h + (i % 4) in element i of block n -- which IS the B operand of a 32x32x2 fp32 MFMA whose two k values are the couts lane
 // halves 0 and 1 hold in the same element: the second conv is NT * 16 MFMAs per M-block on the activated accumulators, no cross-lane movement.
-template <typename T, int KS, int NT, int MT, int NV = 4, bool PW2 = false>
+// GPS: k-groups per weight stage (the fused variant keeps its LDS at 33 KiB: four workgroups of 8 x 16 x 2 pixels per CU instead of one wave per SIMD).
+template <typename T, int KS, int NT, int MT, int NV = 4, bool PW2 = false, int GPS = THIN_GPS>
 __global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
     typedef typename TT<T>::frag frag;
     constexpr int TH = 8 * MT, TW = 16;
@@ -229,10 +230,16 @@ __global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
-    for (int g0 = 0; g0 < KGT; g0 += THIN_GPS) {
-        const int ng = min(THIN_GPS, KGT - g0);
+    for (int g0 = 0; g0 < KGT; g0 += GPS) {
+        const int ng = min(GPS, KGT - g0);
         __syncthreads();
-        {
+        if constexpr (PW2) {
+            // the head's weights are packed for one 32-cout block per workgroup, [cout block][k-group][lane]: this workgroup takes all NT blocks
+            for (int u = tid; u < ng * NT * 64; u += 256) {
+                const int l = u & 63, n = (u >> 6) % NT, gi = (u >> 6) / NT;
+                *reinterpret_cast<f32x4*>(lw + u * 16) = *reinterpret_cast<const f32x4*>(p.w + (((int64_t)n * KGT + g0 + gi) * 64 + l) * 16);
+            }
+        } else {
             const char* wsrc = p.w + ((int64_t)ct * KGT + g0) * (int64_t)(NT * 1024);
             for (int u = tid; u < ng * NT * 64; u += 256)
                 *reinterpret_cast<f32x4*>(lw + u * 16) = *reinterpret_cast<const f32x4*>(wsrc + u * 16);
@@ -311,17 +318,16 @@ int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     return launch_wide_mt<T, KS, KGPT, NT, MT_DEFAULT>(ctx, p0, nct, st);
 }
 
-template <typename T, int KS, int NT, int NV = 4, bool PW2 = false>
+template <typename T, int KS, int NT, int NV = 4, bool PW2 = false, int MT = MT_DEFAULT, int GPS = THIN_GPS>
 int launch_thin(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
-    constexpr int MT = MT_DEFAULT;
     constexpr int PH = 8 * MT + KS - 1, PW = 16 + KS - 1;
     constexpr int KGT = (KS * KS + 1) / 2;
-    constexpr int lds = PH * PW * 16 + (KGT < THIN_GPS ? KGT : THIN_GPS) * NT * 1024;
-    static_assert(!PW2 || (KGT < THIN_GPS ? KGT : THIN_GPS) * NT * 1024 >= NT * 16 * 64 * 4, "the fused 1x1's operands fit the weight stage");
+    constexpr int lds = PH * PW * 16 + (KGT < GPS ? KGT : GPS) * NT * 1024;
+    static_assert(!PW2 || (KGT < GPS ? KGT : GPS) * NT * 1024 >= NT * 16 * 64 * 4, "the fused 1x1's operands fit the weight stage");
     ConvParams p = p0;
     p.tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 8 * MT - 1) / (8 * MT);
-    auto kern = conv_thin_kernel<T, KS, NT, MT, NV, PW2>;
+    auto kern = conv_thin_kernel<T, KS, NT, MT, NV, PW2, GPS>;
     if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
@@ -352,8 +358,13 @@ template <typename T>
 int dispatch(sr_ctx* ctx, const ConvWeights& w, const ConvParams& p, int nct, hipStream_t st) {
     if constexpr (std::is_same<T, float>::value) {
         // SRCNN's head (SRCNN_model.py:50): 9x9 on an RGB image to 96 channels, optionally with the 1x1 that follows it in the epilogue
-        if (w.thin && w.KS == 9 && w.NT == 3 && nct == 1 && w.Cin == 3)
-            return p.pw2w ? launch_thin<T, 9, 3, 3, true>(ctx, p, nct, st) : launch_thin<T, 9, 3, 3, false>(ctx, p, nct, st);
+        // (the packed weights of a thin conv are [cout tile of 32][k-group][lane][4]: NT = 1 with three cout tiles per pixel tile when the head runs alone --
+        // three waves per SIMD, which beat one wave per SIMD at NT = 3 by 1.8x in round 1 --; the fused variant needs all 96 couts of a pixel in one
+        // workgroup and reads the same bytes as [k-group][cout tile] through a stride: see the weight stage)
+        if (w.thin && w.KS == 9 && w.Cin == 3 && w.CoutP == 96) {
+            if (p.pw2w) return launch_thin<T, 9, 3, 3, true, 2, 8>(ctx, p, 1, st);
+            return launch_thin<T, 9, 1, 3, false>(ctx, p, nct, st);
+        }
     }
     if (p.pw2w) return ctx->fail(SR_ERR_INVALID, "conv: the fused 1x1 follows the fp32 9x9 RGB head only");
     if (w.thin) {
@@ -706,7 +717,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         p.pjout = static_cast<char*>(const_cast<void*>(ep.pj_out.p)); p.pj_cs = ep.pj_out.cs; p.pj_coff = ep.pj_out.coff; p.pj_rs = (int)(W * r * ep.pj_out.cs);
     }
     if (ep.pw2) {
-        if (!(w.dtype == SR_DTYPE_F32 && w.thin && !w.few && w.CoutP == 32 * w.NT && ep.pw2->a && ep.pw2->cin == w.Cout && ep.pw2->cout >= 1 && ep.pw2->cout <= 32 && r == 1 &&
+        if (!(w.dtype == SR_DTYPE_F32 && w.thin && !w.few && w.NT == 1 && w.CoutP == 96 && ep.pw2->a && ep.pw2->cin == w.Cout && ep.pw2->cout >= 1 && ep.pw2->cout <= 32 && r == 1 &&
               !p.s1 && !p.s2 && !ep.clip01 && !ep.pj && !ep.f2 && !ep.pool_out.p && !yv.blk && yv.cs - yv.coff >= ep.pw2->cout))
             return ctx->fail(SR_ERR_INVALID, "conv: the fused 1x1 follows an fp32 thin conv that owns all its couts in one workgroup, without skips");
         p.pw2w = ep.pw2->a; p.pw2bias = ep.pw2->bias; p.pw2_cout = ep.pw2->cout; p.pw2_act = ep.pw2->act;
