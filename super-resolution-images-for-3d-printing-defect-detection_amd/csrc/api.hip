@@ -1035,13 +1035,14 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
         if (!m->taps.empty()) {
             auto it = m->taps.find((int)oi);
             if (it != m->taps.end()) {
+                const Op& top = m->ops[oi];                                  // oi may have moved on to a second conv computed in this one's epilogue (the fused 1x1): the tap is on THAT op
                 int C_, mu, sh;
-                op_out_view(m, op, &C_, &mu, &sh);
+                op_out_view(m, top, &C_, &mu, &sh);
                 int th, tw;
-                buf_hw(m->bufs[op.out.buf], H, W, &th, &tw);
+                buf_hw(m->bufs[top.out.buf], H, W, &th, &tw);
                 if (it->second.cap < (int64_t)B * th * tw * C_) return ctx->fail(SR_ERR_CAPACITY, "tap buffer too small");
-                const BufSpec& ob = m->bufs[op.out.buf];
-                rc = tap_copy_launch(ctx, m->bufp[op.out.buf], T, ob.blk, ob.Cbuf, op.out.coff, B, th, tw, C_, it->second.dst, st);
+                const BufSpec& ob = m->bufs[top.out.buf];
+                rc = tap_copy_launch(ctx, m->bufp[top.out.buf], T, ob.blk, ob.Cbuf, top.out.coff, B, th, tw, C_, it->second.dst, st);
                 if (rc) return rc;
             }
         }

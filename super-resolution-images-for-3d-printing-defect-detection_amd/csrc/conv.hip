@@ -188,7 +188,7 @@ constexpr int THIN_GPS = 16;   // k-groups per weight stage
 // output: the workgroup owns all NT * 32 couts of its pixels (gridDim.y == 1).  In the 32x32 accumulator layout lane (r, h) holds, for pixel r of an M-block,
 // couts 32 n + 8 (i / 4) + 4 h + (i % 4) in element i of block n -- which IS the B operand of a 32x32x2 fp32 MFMA whose two k values are the couts lane
 // halves 0 and 1 hold in the same element: the second conv is NT * 16 MFMAs per M-block on the activated accumulators, no cross-lane movement.
-// GPS: k-groups per weight stage (the fused variant keeps its LDS at 33 KiB: four workgroups of 8 x 16 x 2 pixels per CU instead of one wave per SIMD).
+// GPS: k-groups per weight stage (the fused variant: 8 x 16-pixel tiles, 8 k-groups per stage: 30 KiB of LDS and ~110 registers, four workgroups per CU).
 template <typename T, int KS, int NT, int MT, int NV = 4, bool PW2 = false, int GPS = THIN_GPS>
 __global__ void __launch_bounds__(256) conv_thin_kernel(ConvParams p) {
     typedef typename TT<T>::frag frag;
@@ -362,7 +362,9 @@ int dispatch(sr_ctx* ctx, const ConvWeights& w, const ConvParams& p, int nct, hi
         // three waves per SIMD, which beat one wave per SIMD at NT = 3 by 1.8x in round 1 --; the fused variant needs all 96 couts of a pixel in one
         // workgroup and reads the same bytes as [k-group][cout tile] through a stride: see the weight stage)
         if (w.thin && w.KS == 9 && w.Cin == 3 && w.CoutP == 96) {
-            if (p.pw2w) return launch_thin<T, 9, 3, 3, true, 2, 8>(ctx, p, 1, st);
+            // tile height / weight-stage depth measured on 4 x 1024 x 1024 images (round 4, same box): 8 x 16 tiles with 8 k-groups per stage 2.04 ms,
+            // 4 per stage 2.09, 16 x 16 tiles 2.32-2.35, 24 x 16 tiles (one wave per SIMD) 3.05 -- occupancy, not weight traffic, is what this kernel wants
+            if (p.pw2w) return launch_thin<T, 9, 3, 3, true, 1, 8>(ctx, p, 1, st);
             return launch_thin<T, 9, 1, 3, false>(ctx, p, nct, st);
         }
     }
@@ -408,7 +410,10 @@ __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
     const float* inb = reinterpret_cast<const float*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;
     const f32x4* __restrict__ wk = reinterpret_cast<const f32x4*>(p.w);
     const int CinP = p.nchunks * 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // the four couts as two packed pairs: one v_pk_fma_f32 per pair and (tap, cin) -- the pixel value broadcast to both halves, the weight pair
+    // wave-uniform -- where four v_fma_f32 stood (round 4; element by element the same fused multiply-adds in the same order)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     for (int c4 = 0; c4 < p.nchunks; ++c4) {
         __syncthreads();
         for (int u = tid; u < PS * PS; u += 256) {
@@ -428,12 +433,14 @@ __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) {
                     const f32x4 wv = wt[ci];
-#pragma unroll
-                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(xv[ci], wv[co], acc[co]);
+                    const f32x2 xx = {xv[ci], xv[ci]};
+                    acc01 = __builtin_elementwise_fma(xx, f32x2{wv[0], wv[1]}, acc01);
+                    acc23 = __builtin_elementwise_fma(xx, f32x2{wv[2], wv[3]}, acc23);
                 }
             }
     }
     const int oy = y0 + ty, ox = x0 + tx;
+    const float acc[4] = {acc01[0], acc01[1], acc23[0], acc23[1]};
     if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, acc);
 }
 
