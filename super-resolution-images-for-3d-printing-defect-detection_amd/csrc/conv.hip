@@ -410,10 +410,9 @@ __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
     const float* inb = reinterpret_cast<const float*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;
     const f32x4* __restrict__ wk = reinterpret_cast<const f32x4*>(p.w);
     const int CinP = p.nchunks * 4;
-    // the four couts as two packed pairs: one v_pk_fma_f32 per pair and (tap, cin) -- the pixel value broadcast to both halves, the weight pair
-    // wave-uniform -- where four v_fma_f32 stood (round 4; element by element the same fused multiply-adds in the same order)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    // (round 4: the four couts as two v_pk_fma_f32 pairs -- pixel value broadcast by op_sel, weight pair in SGPRs, half the vector instructions -- measured
+    //  0.78 ms against 0.73 for 4 x 1024 x 1024: the loop is not bound by VALU issue; reverted)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c4 = 0; c4 < p.nchunks; ++c4) {
         __syncthreads();
         for (int u = tid; u < PS * PS; u += 256) {
@@ -433,14 +432,12 @@ __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) {
                     const f32x4 wv = wt[ci];
-                    const f32x2 xx = {xv[ci], xv[ci]};
-                    acc01 = __builtin_elementwise_fma(xx, f32x2{wv[0], wv[1]}, acc01);
-                    acc23 = __builtin_elementwise_fma(xx, f32x2{wv[2], wv[3]}, acc23);
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(xv[ci], wv[co], acc[co]);
                 }
             }
     }
     const int oy = y0 + ty, ox = x0 + tx;
-    const float acc[4] = {acc01[0], acc01[1], acc23[0], acc23[1]};
     if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, acc);
 }
 
