@@ -230,6 +230,26 @@ def launch_ranks(n, argv):
     return rc
 
 
+def pmc_traffic(kernel, path=None, fingerprint=None):
+    """Per-launch HBM bytes of `kernel` from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles_r02.sh),
+    or None: the file is quoted only when it was collected on a library built from the kernel sources this run uses (its `_source_sha256` against
+    sr355._lib.source_fingerprint()) -- a kernel change without a re-collection must not leave a stale figure in a driver-written record.
+    -> (bytes or None, note)."""
+    path = path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.isfile(path):
+        return None, "no profiles/pmc_traffic.json"
+    rec = json.load(open(path))
+    if fingerprint is None:
+        from sr355._lib import source_fingerprint
+        fingerprint = source_fingerprint()
+    if rec.get("_source_sha256") != fingerprint:
+        return None, ("profiles/pmc_traffic.json was collected on other kernel sources (sha256 " + str(rec.get("_source_sha256"))[:12] + " != " + fingerprint[:12] +
+                      "): not quoted; re-collect with tools/collect_profiles_r02.sh")
+    if kernel not in rec:
+        return None, "profiles/pmc_traffic.json holds no record for this kernel"
+    return rec[kernel], "profiles/pmc_traffic.json (separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE; kernel sources sha256 " + fingerprint[:12] + ")"
+
+
 def roofline_object(dom, traffic, instrumented_ms_per_step, clock_mhz=None):
     """The `roofline` object of the bench line for the dominant kernel's profile record `dom` = {kernel, launches, total_ms, flops,
     bytes} (sums over its launches; flops / bytes are ALGORITHMIC).  SURVEY.md 8(d) and the north star define this path's roof as
@@ -415,11 +435,9 @@ def main():
         if prof:
             prof.sort(key=lambda r: -r["total_ms"])
             dom = prof[0]
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
-            if os.path.isfile(tp):
-                traffic = json.load(open(tp)).get(dom["kernel"])
+            traffic, traffic_note = pmc_traffic(dom["kernel"])
             roof = roofline_object(dom, traffic, elapsed_prof / args.steps * 1e3, clock_mhz)
+            roof["traffic_source"] = traffic_note
         line = {
             "metric": "4x-SR MPix/s on 512x512 LR batch", "value": mpix * args.steps / elapsed, "unit": "MPix/s",
             "n_gpus": group_world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -461,16 +479,26 @@ def main():
             # A failure here must not cost the headline line.
             from sr355 import bench_rows as BR
             rows = {}
-            for name, fn in (("cfg4_streaming_1080p", lambda: BR.cfg4_streaming(ctx, 3, generator=model)), ("cfg3_train_step", lambda: BR.cfg3_train_step(ctx, 3, 16))):
+            for m_ in models:
+                m_.generator.release_workspace()         # ~115 GB at 16 tiles per call: the rows bring their own
+            jobs = (("cfg4_streaming_1080p", lambda: BR.cfg4_streaming(ctx, 3, generator=model)), ("cfg3_train_step", lambda: BR.cfg3_train_step(ctx, 3, 16)),
+                    ("cfg0_bicubic_psnr_ssim", lambda: BR.cfg0_bicubic_metrics(ctx)), ("cfg1_srcnn_fp32", lambda: BR.cfg1_srcnn(ctx, 32)),
+                    ("a4_edsr_x4", lambda: BR.edsr_x4(ctx)), ("a8_vgg16_classifier", lambda: BR.vgg16_patches(ctx)),
+                    ("whole_tile_forward", lambda: BR.whole_tile(ctx, weights, 2)), ("generator_other_shapes", lambda: BR.generator_shapes(ctx)),
+                    ("attention_wide_logits", lambda: BR.attention_wide_logits(ctx)))
+            for name, fn in jobs:
+                t_row = time.perf_counter()
                 try:
                     r = fn()
                     r.pop("wall_s", None)
                     rows[name] = r
                 except Exception as e:      # noqa: BLE001 -- reported in the line, the headline stands
                     rows[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                rows[name]["row_wall_s"] = round(time.perf_counter() - t_row, 2)
                 if name == "cfg4_streaming_1080p":
                     for m_ in models:
-                        m_.generator.release_workspace()     # the 3600-patch frames grew nothing beyond the 7056-patch step, but the trainer wants room
+                        m_.generator.release_workspace()     # the trainer wants room
+                torch.cuda.empty_cache()
             line["rows"] = rows
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -84,6 +84,20 @@ SIGNATURES = {
 _lib = None
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, in name order): what a measurement taken on one build of the library is tagged with,
+    so that a later build cannot quote it as its own (bench.py refuses a profiles/pmc_traffic.json collected on other sources)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(_HERE), "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def load():
     """Load libsr355.so (once) and declare the prototypes.  Raises if the extension is not built."""
     global _lib

@@ -128,3 +128,22 @@ def test_steps_below_one_is_refused(bench, monkeypatch):
     monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--steps", "0"])
     with pytest.raises(SystemExit):
         bench.main()
+
+
+def test_pmc_traffic_is_quoted_only_for_the_sources_it_was_collected_on(bench, tmp_path):
+    """roofline.traffic comes from a committed file; a kernel change without a re-collection must not leave a stale figure."""
+    from sr355._lib import source_fingerprint
+    fp = source_fingerprint()
+    assert len(fp) == 64 and fp == source_fingerprint()
+    p = tmp_path / "pmc_traffic.json"
+    p.write_text(bench.json.dumps({"dense_tail_fused<bf16,conv4+conv5>": 8.3e9, "_source_sha256": fp}))
+    v, note = bench.pmc_traffic("dense_tail_fused<bf16,conv4+conv5>", str(p))
+    assert v == 8.3e9 and fp[:12] in note
+    v, note = bench.pmc_traffic("some_other_kernel", str(p))
+    assert v is None and "no record" in note
+    p.write_text(bench.json.dumps({"dense_tail_fused<bf16,conv4+conv5>": 8.3e9, "_source_sha256": "0" * 64}))
+    v, note = bench.pmc_traffic("dense_tail_fused<bf16,conv4+conv5>", str(p))
+    assert v is None and "other kernel sources" in note
+    p.write_text(bench.json.dumps({"dense_tail_fused<bf16,conv4+conv5>": 8.3e9}))          # round 3's file: no fingerprint at all
+    assert bench.pmc_traffic("dense_tail_fused<bf16,conv4+conv5>", str(p))[0] is None
+    assert bench.pmc_traffic("x", str(tmp_path / "missing.json")) == (None, "no profiles/pmc_traffic.json")

@@ -40,5 +40,9 @@ for k in range(last - n_per_fwd + 1, last + 1):
 res = {nm: a[1] / a[0] for nm, a in agg.items()}
 res["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB -> B), separate rocprofv3 --pmc passes over tools/probe_trunk.py "
                 f"{sys.argv[4]} patches 48x48 (trunk convs only, no attention); averaged over the launches of one forward")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "super-resolution-images-for-3d-printing-defect-detection_amd"))
+from sr355._lib import source_fingerprint
+res["_source_sha256"] = source_fingerprint()          # bench.py quotes these numbers only for a library built from the same kernel sources
 json.dump(res, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
