@@ -498,7 +498,6 @@ def main():
                 if name == "cfg4_streaming_1080p":
                     for m_ in models:
                         m_.generator.release_workspace()     # the trainer wants room
-                torch.cuda.empty_cache()
             line["rows"] = rows
         print(json.dumps(line), flush=True)
     if world > 1:
