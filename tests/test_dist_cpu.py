@@ -137,3 +137,26 @@ def test_two_rank_data_parallel_gradients():
     # the bucket travels in fp32: the averaged gradient carries fp32 rounding, Adam's first steps are ~lr * sign(g)
     assert np.abs(got - flat).max() <= 2e-5
     assert np.abs(got - np.concatenate([np.asarray(a, np.float64).ravel() for n in sorted(wts) for a in wts[n]])).max() > 5e-4   # it moved
+
+
+def test_partitions_at_world_8():
+    """the shards of BASELINE configs[2] (16 tiles), configs[4] (a stream of frames) and configs[3] (a batch) at the node's 8 ranks:
+    contiguous, disjoint, complete, sizes within one of each other -- for counts that divide, that do not, and that are smaller than the world."""
+    from sr355 import dist as D
+    for n in (16, 3600, 14400, 30, 17, 8, 5, 1, 0):
+        ranges = [D.shard_range(n, r, 8) for r in range(8)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [hi - lo for lo, hi in ranges]
+        assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n and sizes == sorted(sizes, reverse=True)
+    owned = [D.partition_tiles(16, r, 8, "strong")[0] for r in range(8)]
+    assert owned == [[2 * r, 2 * r + 1] for r in range(8)]
+    # the cfg4 stream: stream_sr_classify takes frames[lo:hi] of shard_range(len(frames), rank, world) -- 30 frames at 8 ranks: 4,4,4,4,4,4,3,3
+    assert [hi - lo for lo, hi in (D.shard_range(30, r, 8) for r in range(8))] == [4, 4, 4, 4, 4, 4, 3, 3]
+    # the dense-block kernels' row partition at a rank's share (csrc/dense_fused.hip): a range of R stream rows costs ceil((R + 3) / 8) eight-row steps
+    # (one warm-up row at either end, the second layer one row behind), so 882 patches x 49 rows on 256 workgroups = 169 rows each take 22 steps where
+    # 21.5 would do -- the 4 % of profiles/r0*_tiles_sweep.jsonl at 2 tiles; 7056 patches: 1351 rows, 170 steps, 99.3 % of the slots
+    steps = lambda rows: -(-(rows + 3) // 8)
+    for patches, want in ((882, 22), (7056, 170), (1764, 43), (3528, 85)):
+        rows = -(-patches * 49 // 256)
+        assert steps(rows) == want, (patches, rows, steps(rows))
