@@ -292,6 +292,9 @@ def main():
     ap.add_argument("--raw-glorot", action="store_true",
                     help="round 1's weights: glorot without conditioning the attention logits (sr355.weights.condition_attention)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--zero-data", action="store_true",
+                    help="DIAGNOSTIC, not a result: all-zero weights and tiles -- the same launches with no bit toggling in the operands (MI355X_MICROARCH.md DVFS item 1): what the "
+                         "kernels' times become when the chip does not give clock back to data-dependent power; the line says so in `data`")
     ap.add_argument("--no-rows", action="store_true", help="skip the other BASELINE rows (cfg3 training step, cfg4 streaming) that the N = 1 line carries beside the headline")
     ap.add_argument("--fused", type=int, default=511,
                     help="dense-block conv pairs run as one fused kernel: bit 0 conv4+conv5, bit 1 conv2+conv3, bit 2 final_conv2 inside final_conv1, bit 3 attention projections inside the producing conv (0 = layer by layer, for A/B runs)")
@@ -340,6 +343,8 @@ def main():
             if not args.raw_glorot:
                 weights = condition_attention(weights)
             weights = bf16_rounded(weights)      # what the device holds anyway; the oracle then sees bit-identical parameters
+            if args.zero_data:
+                weights = {n: (np.zeros_like(k), np.zeros_like(b)) for n, (k, b) in weights.items()}
         m_.set_weights(weights)
         models.append(m_)
     model = models[0]
@@ -349,6 +354,8 @@ def main():
     # a rank holds only its own shard of the batch in HBM
     seed = 42 + 2 + (1000 * rank if scaling == "weak" else 0)
     lr4, hr4 = make_pairs(4, LR, LR, SCALE, seed=seed)
+    if args.zero_data:
+        lr4, hr4 = np.full_like(lr4, 0.5), np.full_like(hr4, 0.5)      # 0.5 -> 0.0 after the generator's [0, 1] -> [-1, 1] rescale
     lr = ctx.to_device(np.stack([lr4[t % 4] for t in my_tiles])) if n_mine else None
     hr = ctx.to_device(np.stack([hr4[t % 4] for t in my_tiles])) if n_mine else None
     sums = torch.zeros(3, dtype=torch.float64, device=ctx.torch_device)
@@ -443,7 +450,8 @@ def main():
             "n_gpus": group_world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_median_device": median_ms, "value_at_median_step": mpix / (median_ms * 1e-3),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic (seeded 3D-print tiles; seeded glorot-uniform weights" + ("" if args.raw_glorot else
+            "data": ("DIAGNOSTIC --zero-data: all-zero weights and tiles (clock / power experiment, not a throughput result); " if args.zero_data else "") +
+                    "synthetic (seeded 3D-print tiles; seeded glorot-uniform weights" + ("" if args.raw_glorot else
                     ", attention logits conditioned by 2^-8: sr355.weights.condition_attention") + ")",
             "config": {"workload": f"BASELINE configs[2]: ESRGAN-RRDB x4 (NB=23,G=32,2xSelfAttention) on a batch of {global_tiles} LR tiles 512x512, "
                                    "reference patch mode p=48 s=24 (441 patches/tile)" + (" [NO-ATTENTION tuning variant]" if args.no_attention else ""),
@@ -465,7 +473,7 @@ def main():
         kept = {}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, lr4[0], keep=kept)
-        if world == 1 and not args.no_parity and not args.no_attention:
+        if world == 1 and not args.no_parity and not args.no_attention and not args.zero_data:
             line["parity"] = parity_object(ctx, model, weights, lr4[0], hr4[0], kept.get("fp32_reference_graph"))
             line["parity"]["weights"] = "the timed step's: seeded glorot-uniform (PSNR vs HR ~9.6 dB: the generator's output is noise relative to HR)"
             # the same figures where they can fail: a generator whose output resembles HR
@@ -474,7 +482,7 @@ def main():
             except Exception as e:      # noqa: BLE001 -- reported in the line, the headline stands
                 line["parity_trained_like"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             model.set_weights(weights)
-        if world == 1 and not args.no_rows and not args.no_attention:
+        if world == 1 and not args.no_rows and not args.no_attention and not args.zero_data:
             # BASELINE configs[3] and configs[4] beside the headline, outside its timed region (~25 s): so that the driver's record carries them.
             # A failure here must not cost the headline line.
             from sr355 import bench_rows as BR
