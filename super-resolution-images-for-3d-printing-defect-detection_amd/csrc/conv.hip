@@ -179,6 +179,140 @@ __global__ void __launch_bounds__(256) conv_wide_kernel(ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// wide kernel, split-K inside the workgroup (fp32, 3x3; round 4).  The training step's layers are SMALL: 16 patches of 24 x 24 are 9216 pixels,
+// 72 of the 8 x 16 tiles above on 256 CUs, and every one of their waves walks the whole K = 9 * Cin alone (conv5 of a dense block: 1728 fp32
+// MFMAs of 64 cycles, 67 us for 2 GFLOP = 20 % of the fp32 peak, profiles/r03_cfg3_train_kernel_stats.csv).  Here a workgroup owns ONE M-block
+// (2 rows x 16 columns = the 32 columns of one MFMA) and its four waves share the k-groups of every staged chunk (wave w takes k-groups w, w + 4, ...);
+// at the end the four partial accumulators meet in LDS and wave w adds them -- always in the order 0, 1, 2, 3: deterministic, no atomics -- for the
+// four-cout groups q = w, then runs the usual epilogue.  Four times the workgroups, a quarter of the serial MFMA chain each; the weights of a chunk
+// are staged per 32 pixels instead of per 128 (L2 -> LDS at 59 B/clk per CU: ~3.5 us for conv5's 432 KiB, under the 13 us of MFMAs).
+// ------------------------------------------------------------------------------------------------
+template <int KS, int KGPT, int NT>
+__global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
+    typedef f32x4 frag;
+    constexpr int E = 4;
+    constexpr int TH = 2, TW = 16;
+    constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PADK = (KS - 1) / 2, NTAP = KS * KS;
+    constexpr int SPP = KGPT * 2;
+    constexpr int CS = KGPT * 32 + 16;
+    constexpr int NIN = PH * PW * SPP;
+    constexpr int NINT = (NIN + 255) / 256;
+    constexpr int NKG = NTAP * KGPT;
+    constexpr int WUNITS = NKG * NT * 64;
+    constexpr int LIN_BYTES = (PH * PW * CS + 15) & ~15;
+    static_assert(WUNITS * 16 >= 4 * NT * 16 * 64 * 4, "the reduction reuses the weight stage");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lin = smem;
+    char* lw = smem + LIN_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    int t = blockIdx.x;
+    const int tx = t % p.tilesX; t /= p.tilesX;
+    const int ty = t % p.tilesY;
+    const int b = t / p.tilesY;
+    const int ct = blockIdx.y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* inb = reinterpret_cast<const float*>(p.in) + (int64_t)b * p.H * p.W * p.in_cs + p.in_coff;
+
+    int soff[NINT], doff[NINT];
+#pragma unroll
+    for (int i = 0; i < NINT; ++i) {
+        const int u = tid + 256 * i;
+        const int pix = u / SPP, sl = u - pix * SPP;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = y0 + py - PADK, gx = x0 + px - PADK;
+        const bool live = u < NIN;
+        const bool inside = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        doff[i] = live ? pix * CS + sl * 16 : -1;
+        soff[i] = inside ? (int)(((int64_t)gy * p.W + gx) * p.in_cs) + sl * E : -1;
+    }
+    frag pre[NINT];
+    auto issue = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NINT; ++i) {
+            const int so = soff[i];
+            frag v = *reinterpret_cast<const frag*>(inb + (so >= 0 ? so + chunk * (SPP * E) : 0));
+            frag z = {};
+            pre[i] = so >= 0 ? v : z;
+        }
+    };
+    const int abase = ((r >> 4) * PW + (r & 15)) * CS + h * 16;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+
+    issue(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NINT; ++i)
+            if (doff[i] >= 0) *reinterpret_cast<frag*>(lin + doff[i]) = pre[i];
+        {
+            const char* wsrc = p.w + ((int64_t)ct * p.nchunks + chunk) * (int64_t)(WUNITS * 16);
+            for (int u = tid; u < WUNITS; u += 256)
+                *reinterpret_cast<f32x4*>(lw + u * 16) = *reinterpret_cast<const f32x4*>(wsrc + u * 16);
+        }
+        __syncthreads();
+        if (chunk + 1 < p.nchunks) issue(chunk + 1);
+#pragma unroll
+        for (int g0 = 0; g0 < NKG; g0 += 4) {
+            const int g = g0 + wave;                               // wave-uniform
+            if (g < NKG) {
+                const int tap = g / KGPT, kg = g - tap * KGPT;
+                const int toff = ((tap / KS) * PW + (tap % KS)) * CS;
+                const frag xf = *reinterpret_cast<const frag*>(lin + abase + toff + kg * 32);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const frag wf = *reinterpret_cast<const frag*>(lw + (g * NT + n) * 1024 + lane * 16);
+                    acc[n] = mma(wf, xf, acc[n]);
+                }
+            }
+        }
+    }
+    // the four partial sums of every output meet in LDS (the weight stage is free now) and are added in wave order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lw);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[((wave * NT + n) * 16 + i) * 64 + lane] = acc[n][i];
+    __syncthreads();
+    const int oy = y0 + (r >> 4), ox = x0 + (r & 15);
+    if (oy >= p.H || ox >= p.W) return;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * wave + e;
+            float v = red[((0 * NT + n) * 16 + i) * 64 + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) v += red[((w2 * NT + n) * 16 + i) * 64 + lane];
+            a[e] = v;
+        }
+        epilogue4<float>(p, b, oy, ox, (ct * NT + n) * 32 + 8 * wave + 4 * h, a);
+    }
+}
+
+template <int KS, int KGPT, int NT>
+int launch_wide_sk(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
+    constexpr int PH = 2 + KS - 1, PW = 16 + KS - 1;
+    constexpr int CS = KGPT * 32 + 16;
+    constexpr int lds = ((PH * PW * CS + 15) & ~15) + KS * KS * KGPT * NT * 1024;
+    ConvParams p = p0;
+    p.tilesX = (p.W + 15) / 16;
+    p.tilesY = (p.H + 1) / 2;
+    auto kern = conv_wide_sk_kernel<KS, KGPT, NT>;
+    if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+    dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // thin kernel: one 16-byte slice per pixel holds every input channel (RGB padded to 8 bf16 / 4 fp32)
 // ------------------------------------------------------------------------------------------------
 constexpr int THIN_GPS = 16;   // k-groups per weight stage
@@ -313,6 +447,12 @@ int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     // times the workgroups and a third of the serial work each.  (bf16 inference never gets here with so few pixels.)
     if constexpr (std::is_same<T, float>::value) {
         const int64_t wgs3 = (int64_t)((p0.W + 15) / 16) * ((p0.H + 8 * MT_DEFAULT - 1) / (8 * MT_DEFAULT)) * p0.B * nct;
+        if constexpr (KS == 3 && KGPT == 2) {
+            // still fewer than one 8 x 16 tile per CU: split K inside the workgroup (conv_wide_sk_kernel) -- 4 x the workgroups, a quarter of the chain each
+            static const bool no_sk = getenv("SR355_NO_SPLITK") != nullptr;      // A/B switch (diagnostic)
+            const int64_t wgs1 = (int64_t)((p0.W + 15) / 16) * ((p0.H + 7) / 8) * p0.B * nct;
+            if (!no_sk && wgs1 < ctx->cu_count()) return launch_wide_sk<KS, KGPT, NT>(ctx, p0, nct, st);
+        }
         if (wgs3 < 2 * ctx->cu_count()) return launch_wide_mt<T, KS, KGPT, NT, 1>(ctx, p0, nct, st);
     }
     return launch_wide_mt<T, KS, KGPT, NT, MT_DEFAULT>(ctx, p0, nct, st);
