@@ -226,7 +226,10 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
         doff[i] = live ? pix * CS + sl * 16 : -1;
         soff[i] = inside ? (int)(((int64_t)gy * p.W + gx) * p.in_cs) + sl * E : -1;
     }
-    frag pre[NINT];
+    // both the next chunk's pixels and its weights fly under the current chunk's MFMAs: with a quarter of the chain per wave the weight stage's
+    // round trip (36 KiB per chunk at NT = 2) would otherwise be as long as the chunk's arithmetic
+    constexpr int NWT = (WUNITS + 255) / 256;
+    frag pre[NINT], wpre[NWT];
     auto issue = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < NINT; ++i) {
@@ -234,6 +237,12 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
             frag v = *reinterpret_cast<const frag*>(inb + (so >= 0 ? so + chunk * (SPP * E) : 0));
             frag z = {};
             pre[i] = so >= 0 ? v : z;
+        }
+        const char* wsrc = p.w + ((int64_t)ct * p.nchunks + chunk) * (int64_t)(WUNITS * 16);
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int u = tid + 256 * i;
+            wpre[i] = *reinterpret_cast<const f32x4*>(wsrc + (u < WUNITS ? u : 0) * 16);
         }
     };
     const int abase = ((r >> 4) * PW + (r & 15)) * CS + h * 16;
@@ -249,10 +258,10 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < NINT; ++i)
             if (doff[i] >= 0) *reinterpret_cast<frag*>(lin + doff[i]) = pre[i];
-        {
-            const char* wsrc = p.w + ((int64_t)ct * p.nchunks + chunk) * (int64_t)(WUNITS * 16);
-            for (int u = tid; u < WUNITS; u += 256)
-                *reinterpret_cast<f32x4*>(lw + u * 16) = *reinterpret_cast<const f32x4*>(wsrc + u * 16);
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int u = tid + 256 * i;
+            if (u < WUNITS) *reinterpret_cast<f32x4*>(lw + u * 16) = wpre[i];
         }
         __syncthreads();
         if (chunk + 1 < p.nchunks) issue(chunk + 1);

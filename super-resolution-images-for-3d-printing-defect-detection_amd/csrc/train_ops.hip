@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int WG_SPLIT_PIX = 2048;        // pixels per workgroup slice of the reduction axis
+constexpr int WG_SPLIT_PIX = 512;         // pixels per workgroup slice of the reduction axis (round 3: 2048)
 
 __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS,
                                                             int nci, int nco, int nsplit, float* partial) {
@@ -35,13 +35,15 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
     // carried along instead of being divided out of pp every time, and eight pixel pairs' operands are requested before the eight MFMAs that
     // consume them (round 2: one dependent pair of loads in front of every MFMA -- a launch ran at the latency of 256 serial loads, 151 us
     // for 0.2 GFLOP).  The MFMAs still run in pixel order, so the sums are bit for bit the ones of round 2.
+    // Round 4: two batches in flight -- the operands of batch n + 1 are requested before the MFMAs of batch n (a launch still ran at ~1 us of load
+    // latency per eight MFMAs: 56 us for conv5's 2 GFLOP) -- and four times the pixel slices per layer (WG_SPLIT_PIX), so that a CU holds ~8
+    // workgroups instead of 2.  The MFMAs of a slice still run in pixel order.
     constexpr int U = 8;
     int64_t pp = p0 + 2 * wave + k;
     int xq = (int)(pp % W);
     int64_t r = pp / W;                     // image row counted through the batch
     int yq = (int)(r % H);
-    for (int64_t pb = p0 + 2 * wave; pb < p1; pb += 8 * U) {
-        float a[U], bv[U];
+    auto fetch = [&](float (&a)[U], float (&bv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool live = pp < p1;
@@ -55,8 +57,16 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
             xq += 8;
             while (xq >= W) { xq -= W; ++r; if (++yq == H) yq = 0; }
         }
+    };
+    float a0[U], b0[U], a1[U], b1[U];
+    fetch(a0, b0);
+    for (int64_t pb = p0 + 2 * wave; pb < p1; pb += 16 * U) {
+        fetch(a1, b1);                      // (past the slice's end: zeros, from a valid address)
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+        fetch(a0, b0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
     }
     // sum the 4 waves' tiles through LDS, fixed order
     __shared__ float red[4][32 * 32];
@@ -86,15 +96,23 @@ __global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit
     }
 }
 
-__global__ void colsum_kernel(const float* dy, int64_t P, int C, float* out) {
-    __shared__ double red[256];
-    const int c = blockIdx.x;
+// bias gradient: column sums of dy [P][C].  One workgroup per 32 channels, thread (channel, pixel lane): for a fixed pixel the 32 channels are one
+// 128-byte line (round 3: one workgroup per channel, every lane on its own line -- 14 us for 9216 x 64); double accumulation, the 32 pixel lanes summed
+// in a fixed order.
+__global__ void __launch_bounds__(1024) colsum_kernel(const float* dy, int64_t P, int C, float* out) {
+    __shared__ double red[32][33];
+    const int ci = threadIdx.x & 31, pj = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + ci;
     double s = 0.0;
-    for (int64_t p = threadIdx.x; p < P; p += blockDim.x) s += (double)dy[p * C + c];
-    red[threadIdx.x] = s;
+    if (c < C)
+        for (int64_t p = pj; p < P; p += 32) s += (double)dy[p * C + c];
+    red[pj][ci] = s;
     __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) out[c] = (float)red[0];
+    if (pj == 0 && c < C) {
+        double t = 0.0;
+        for (int j = 0; j < 32; ++j) t += red[j][ci];
+        out[c] = (float)t;
+    }
 }
 
 __global__ void eltwise_kernel(int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n) {
@@ -322,7 +340,7 @@ int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int
     if (!partial) return SR_ERR_OOM;
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial);
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw);
-    if (db) hipLaunchKernelGGL(colsum_kernel, dim3(Cout), dim3(256), 0, st, dy, P, Cout, db);
+    if (db) hipLaunchKernelGGL(colsum_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, st, dy, P, Cout, db);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }
