@@ -15,7 +15,7 @@ namespace {
 constexpr int WG_SPLIT_PIX = 512;         // pixels per workgroup slice of the reduction axis (round 3: 2048)
 
 __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS,
-                                                            int nci, int nco, int nsplit, float* partial) {
+                                                            int nci, int nco, int nsplit, float* partial, double* bpart) {
     // blockIdx.x = ((tap * nci) + cib) * nco + cob, blockIdx.y = split
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5;
     int t = blockIdx.x;
@@ -43,6 +43,10 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
     int xq = (int)(pp % W);
     int64_t r = pp / W;                     // image row counted through the batch
     int yq = (int)(r % H);
+    // the bias gradient rides along (round 4; round 3 launched a column-sum kernel per layer): the workgroups of tap 0 / input block 0 see every dy value
+    // of their slice as the B operand -- each lane adds its own up in double, the lanes of a cout meet in LDS below
+    const bool do_b = bpart != nullptr && tap == 0 && cib == 0;
+    double bsum = 0.0;
     auto fetch = [&](float (&a)[U], float (&bv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -64,9 +68,17 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
         fetch(a1, b1);                      // (past the slice's end: zeros, from a valid address)
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
+        if (do_b) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) bsum += (double)b0[u];
+        }
         fetch(a0, b0);
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
+        if (do_b) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) bsum += (double)b1[u];
+        }
     }
     // sum the 4 waves' tiles through LDS, fixed order
     __shared__ float red[4][32 * 32];
@@ -78,9 +90,19 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
     __syncthreads();
     float* out = partial + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024);
     for (int e = threadIdx.x; e < 1024; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (do_b) {
+        __shared__ double bred[8][32];
+        bred[wave * 2 + k][i] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double t = 0.0;
+            for (int j = 0; j < 8; ++j) t += bred[j][threadIdx.x];
+            bpart[((size_t)blockIdx.y * nco + cob) * 32 + threadIdx.x] = t;
+        }
+    }
 }
 
-__global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit, int Cin, int Cout, int nci, int nco, float* dw) {
+__global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit, int Cin, int Cout, int nci, int nco, float* dw, const double* bpart, float* db) {
     // one thread per element of one 32x32 tile; dw is HWIO [tap][Cin][Cout]
     const int tile = blockIdx.x;
     int t = tile;
@@ -94,24 +116,10 @@ __global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit
         for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * ntiles + tile) * 1024 + e];
         dw[((size_t)tap * Cin + ci) * Cout + co] = s;
     }
-}
-
-// bias gradient: column sums of dy [P][C].  One workgroup per 32 channels, thread (channel, pixel lane): for a fixed pixel the 32 channels are one
-// 128-byte line (round 3: one workgroup per channel, every lane on its own line -- 14 us for 9216 x 64); double accumulation, the 32 pixel lanes summed
-// in a fixed order.
-__global__ void __launch_bounds__(1024) colsum_kernel(const float* dy, int64_t P, int C, float* out) {
-    __shared__ double red[32][33];
-    const int ci = threadIdx.x & 31, pj = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + ci;
-    double s = 0.0;
-    if (c < C)
-        for (int64_t p = pj; p < P; p += 32) s += (double)dy[p * C + c];
-    red[pj][ci] = s;
-    __syncthreads();
-    if (pj == 0 && c < C) {
-        double t = 0.0;
-        for (int j = 0; j < 32; ++j) t += red[j][ci];
-        out[c] = (float)t;
+    if (db && tap == 0 && cib == 0 && threadIdx.x < 32 && cob * 32 + (int)threadIdx.x < Cout) {
+        double t2 = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) t2 += bpart[((size_t)sp * nco + cob) * 32 + threadIdx.x];
+        db[cob * 32 + threadIdx.x] = (float)t2;
     }
 }
 
@@ -336,11 +344,12 @@ int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int
     int nsplit = (int)((P + WG_SPLIT_PIX - 1) / WG_SPLIT_PIX);
     if (nsplit > 64) nsplit = 64;
     if (nsplit < 1) nsplit = 1;
-    float* partial = static_cast<float*>(ctx->scratch((size_t)nsplit * ntiles * 1024 * sizeof(float)));
+    const size_t tile_bytes = (size_t)nsplit * ntiles * 1024 * sizeof(float);
+    float* partial = static_cast<float*>(ctx->scratch(tile_bytes + (size_t)nsplit * nco * 32 * sizeof(double)));
     if (!partial) return SR_ERR_OOM;
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial);
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw);
-    if (db) hipLaunchKernelGGL(colsum_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, st, dy, P, Cout, db);
+    double* bpart = db ? reinterpret_cast<double*>(reinterpret_cast<char*>(partial) + tile_bytes) : nullptr;
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial, bpart);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, bpart, db);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }
