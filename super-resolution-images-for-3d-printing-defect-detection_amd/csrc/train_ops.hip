@@ -12,10 +12,10 @@
 
 namespace {
 
-constexpr int WG_SPLIT_PIX = 2048;        // pixels per workgroup slice of the reduction axis (generic kernel; 512 measured slower: 68 us against 56 per layer)
+constexpr int WG_SPLIT_PIX = 2048;        // pixels per workgroup slice of the reduction axis
 
 __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS,
-                                                            int nci, int nco, int nsplit, float* partial, double* bpart) {
+                                                            int nci, int nco, int nsplit, float* partial) {
     // blockIdx.x = ((tap * nci) + cib) * nco + cob, blockIdx.y = split
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5;
     int t = blockIdx.x;
@@ -35,19 +35,13 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
     // carried along instead of being divided out of pp every time, and eight pixel pairs' operands are requested before the eight MFMAs that
     // consume them (round 2: one dependent pair of loads in front of every MFMA -- a launch ran at the latency of 256 serial loads, 151 us
     // for 0.2 GFLOP).  The MFMAs still run in pixel order, so the sums are bit for bit the ones of round 2.
-    // Round 4: two batches in flight -- the operands of batch n + 1 are requested before the MFMAs of batch n (a launch still ran at ~1 us of load
-    // latency per eight MFMAs: 56 us for conv5's 2 GFLOP) -- and four times the pixel slices per layer (WG_SPLIT_PIX), so that a CU holds ~8
-    // workgroups instead of 2.  The MFMAs of a slice still run in pixel order.
     constexpr int U = 8;
     int64_t pp = p0 + 2 * wave + k;
     int xq = (int)(pp % W);
     int64_t r = pp / W;                     // image row counted through the batch
     int yq = (int)(r % H);
-    // the bias gradient rides along (round 4; round 3 launched a column-sum kernel per layer): the workgroups of tap 0 / input block 0 see every dy value
-    // of their slice as the B operand -- each lane adds its own up in double, the lanes of a cout meet in LDS below
-    const bool do_b = bpart != nullptr && tap == 0 && cib == 0;
-    double bsum = 0.0;
-    auto fetch = [&](float (&a)[U], float (&bv)[U]) {
+    for (int64_t pb = p0 + 2 * wave; pb < p1; pb += 8 * U) {
+        float a[U], bv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool live = pp < p1;
@@ -61,24 +55,8 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
             xq += 8;
             while (xq >= W) { xq -= W; ++r; if (++yq == H) yq = 0; }
         }
-    };
-    float a0[U], b0[U], a1[U], b1[U];
-    fetch(a0, b0);
-    for (int64_t pb = p0 + 2 * wave; pb < p1; pb += 16 * U) {
-        fetch(a1, b1);                      // (past the slice's end: zeros, from a valid address)
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0);
-        if (do_b) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) bsum += (double)b0[u];
-        }
-        fetch(a0, b0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0);
-        if (do_b) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) bsum += (double)b1[u];
-        }
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
     }
     // sum the 4 waves' tiles through LDS, fixed order
     __shared__ float red[4][32 * 32];
@@ -90,109 +68,9 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
     __syncthreads();
     float* out = partial + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 1024);
     for (int e = threadIdx.x; e < 1024; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    if (do_b) {
-        __shared__ double bred[8][32];
-        bred[wave * 2 + k][i] = bsum;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            double t = 0.0;
-            for (int j = 0; j < 8; ++j) t += bred[j][threadIdx.x];
-            bpart[((size_t)blockIdx.y * nco + cob) * 32 + threadIdx.x] = t;
-        }
-    }
 }
 
-// 3x3 layers (all but a handful of the training step's convs): ONE workgroup computes all nine taps of its (input block, cout block, pixel slice) -- the dy
-// value of a pixel is loaded once and meets nine shifted x values in nine accumulator tiles (round 3: a workgroup per tap, two loads per MFMA, 540 workgroups of
-// ~230 latency-bound MFMAs for conv5 of a dense block: 56 us for 2 GFLOP).  Pixel order inside a slice, fixed-order reductions: deterministic as before.
-__global__ void __launch_bounds__(256) wgrad3_partial_kernel(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int nci, int nco, int nsplit,
-                                                             float* partial, double* bpart) {
-    // blockIdx.x = cib * nco + cob, blockIdx.y = split; partial tile index = (tap * nci + cib) * nco + cob (wgrad_finish_kernel's)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5;
-    const int cob = blockIdx.x % nco, cib = blockIdx.x / nco;
-    const int ci = cib * 32 + i, co = cob * 32 + i;
-    const bool ci_ok = ci < Cin, co_ok = co < Cout;
-    const int64_t P = (int64_t)B * H * W;
-    const int64_t per = (P + nsplit - 1) / nsplit;
-    const int64_t p0 = (int64_t)blockIdx.y * per, p1 = min(P, p0 + per);
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    const bool do_b = bpart != nullptr && cib == 0;
-    double bsum = 0.0;
-    constexpr int U = 4;
-    int64_t pp = p0 + 2 * wave + k;
-    int xq = (int)(pp % W);
-    int64_t r = pp / W;
-    int yq = (int)(r % H);
-    auto fetch = [&](float (&a)[U][9], float (&bv)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool live = pp < p1;
-            const float bw = dy[(live && co_ok) ? pp * Cout + co : 0];
-            bv[u] = (live && co_ok) ? bw : 0.f;
-            const int64_t rowbase = (r - yq) * W;                  // first pixel of this image
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int sy = yq + ky - 1, sx = xq + kx - 1;
-                    const bool in = live && ci_ok && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
-                    const float av = x[in ? (rowbase + (int64_t)sy * W + sx) * Cin + ci : 0];
-                    a[u][ky * 3 + kx] = in ? av : 0.f;
-                }
-            pp += 8;
-            xq += 8;
-            while (xq >= W) { xq -= W; ++r; if (++yq == H) yq = 0; }
-        }
-    };
-    auto consume = [&](const float (&a)[U][9], const float (&bv)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], bv[u], acc[t], 0, 0, 0);
-            if (do_b) bsum += (double)bv[u];
-        }
-    };
-    float a0[U][9], b0[U], a1[U][9], b1[U];
-    fetch(a0, b0);
-    for (int64_t pb = p0 + 2 * wave; pb < p1; pb += 16 * U) {
-        fetch(a1, b1);
-        consume(a0, b0);
-        fetch(a0, b0);
-        consume(a1, b1);
-    }
-    __shared__ float red[4][32 * 32];
-    for (int t = 0; t < 9; ++t) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * k;
-            float v = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < 9; ++tt) v = tt == t ? acc[tt][e] : v;      // (a runtime index into the accumulators would send them to scratch)
-            red[wave][row * 32 + i] = v;
-        }
-        __syncthreads();
-        const int tile = (t * nci + cib) * nco + cob;
-        float* out = partial + (((size_t)blockIdx.y * (9 * nci * nco) + tile) * 1024);
-        for (int e = threadIdx.x; e < 1024; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    }
-    if (do_b) {
-        __shared__ double bred[8][32];
-        bred[wave * 2 + k][i] = bsum;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            double t2 = 0.0;
-            for (int j = 0; j < 8; ++j) t2 += bred[j][threadIdx.x];
-            bpart[((size_t)blockIdx.y * nco + cob) * 32 + threadIdx.x] = t2;
-        }
-    }
-}
-
-__global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit, int Cin, int Cout, int nci, int nco, float* dw, const double* bpart, float* db) {
+__global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit, int Cin, int Cout, int nci, int nco, float* dw) {
     // one thread per element of one 32x32 tile; dw is HWIO [tap][Cin][Cout]
     const int tile = blockIdx.x;
     int t = tile;
@@ -203,15 +81,20 @@ __global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit
         const int ci = cib * 32 + e / 32, co = cob * 32 + (e & 31);
         if (ci >= Cin || co >= Cout) continue;
         float s = 0.f;
-#pragma unroll 8
         for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * ntiles + tile) * 1024 + e];
         dw[((size_t)tap * Cin + ci) * Cout + co] = s;
     }
-    if (db && tap == 0 && cib == 0 && threadIdx.x < 32 && cob * 32 + (int)threadIdx.x < Cout) {
-        double t2 = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) t2 += bpart[((size_t)sp * nco + cob) * 32 + threadIdx.x];
-        db[cob * 32 + threadIdx.x] = (float)t2;
-    }
+}
+
+__global__ void colsum_kernel(const float* dy, int64_t P, int C, float* out) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int64_t p = threadIdx.x; p < P; p += blockDim.x) s += (double)dy[p * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[c] = (float)red[0];
 }
 
 __global__ void eltwise_kernel(int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n) {
@@ -432,28 +315,14 @@ int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int
     if (KS < 1 || !(KS & 1) || KS > 15) return ctx->fail(SR_ERR_INVALID, "wgrad: odd kernel sizes up to 15 only");
     const int nci = (Cin + 31) / 32, nco = (Cout + 31) / 32, ntiles = KS * KS * nci * nco;
     const int64_t P = (int64_t)B * H * W;
-    static const bool old_path = getenv("SR355_WGRAD_PER_TAP") != nullptr;      // A/B switch (diagnostic)
-    const bool nine = KS == 3 && !old_path;
-    int nsplit;
-    if (nine) {
-        // enough pixel slices to put a workgroup on every CU, none shorter than 256 pixels (a wave then still runs 32 pixel pairs x 9 MFMAs)
-        nsplit = (ctx->cu_count() + nci * nco - 1) / (nci * nco);
-        const int64_t cap = (P + 255) / 256;
-        if (nsplit > cap) nsplit = (int)cap;
-    } else {
-        nsplit = (int)((P + WG_SPLIT_PIX - 1) / WG_SPLIT_PIX);
-    }
+    int nsplit = (int)((P + WG_SPLIT_PIX - 1) / WG_SPLIT_PIX);
     if (nsplit > 64) nsplit = 64;
     if (nsplit < 1) nsplit = 1;
-    const size_t tile_bytes = (size_t)nsplit * ntiles * 1024 * sizeof(float);
-    float* partial = static_cast<float*>(ctx->scratch(tile_bytes + (size_t)nsplit * nco * 32 * sizeof(double)));
+    float* partial = static_cast<float*>(ctx->scratch((size_t)nsplit * ntiles * 1024 * sizeof(float)));
     if (!partial) return SR_ERR_OOM;
-    double* bpart = db ? reinterpret_cast<double*>(reinterpret_cast<char*>(partial) + tile_bytes) : nullptr;
-    if (nine)
-        hipLaunchKernelGGL(wgrad3_partial_kernel, dim3(nci * nco, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, nci, nco, nsplit, partial, bpart);
-    else
-        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial, bpart);
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, bpart, db);
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw);
+    if (db) hipLaunchKernelGGL(colsum_kernel, dim3(Cout), dim3(256), 0, st, dy, P, Cout, db);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }
