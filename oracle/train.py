@@ -116,7 +116,15 @@ def _act(x, act):
     return x
 
 
-def _conv_s(x, k, b, act=None, stride=1):
+def _masked_act(y, act, mask):
+    """The activation with its branch taken from `mask` (bool, y > 0 as ANOTHER evaluation of the same graph saw it) instead of from y's own sign:
+    two correct forward passes that differ in their last bits disagree about the branch at the few elements whose pre-activation is within rounding
+    error of zero, and each such element moves a gradient by a whole unit of slope; with the branches pinned the comparison is about arithmetic."""
+    m = mask.to(y.dtype)
+    return y * m if act == "relu" else y * (m + 0.2 * (1.0 - m))
+
+
+def _conv_s(x, k, b, act=None, stride=1, mask=None):
     """Keras Conv2D SAME with TF's asymmetric padding for stride 2; x NCHW."""
     kt = k.permute(3, 2, 0, 1)
     kh = k.shape[0]
@@ -125,7 +133,8 @@ def _conv_s(x, k, b, act=None, stride=1):
         out = -(-n // stride)
         tot = max((out - 1) * stride + kh - n, 0)
         pads += [tot // 2, tot - tot // 2]
-    return _act(F.conv2d(F.pad(x, pads), kt, b, stride=stride), act)
+    y = F.conv2d(F.pad(x, pads), kt, b, stride=stride)
+    return _masked_act(y, act, mask) if (mask is not None and act in ("relu", "lrelu")) else _act(y, act)
 
 
 def _sa_t(p, x, name):
@@ -140,7 +149,9 @@ def _sa_t(p, x, name):
     return x + _conv_s(o, *p[name + "_v"])
 
 
-def generator_forward_t(p, x, scale, num_rrdb, attention=True):
+def generator_forward_t(p, x, scale, num_rrdb, attention=True, masks=None):
+    """masks: {layer: bool NCHW tensor} -- activation branches pinned to another evaluation's (see _masked_act); layers not in it use their own."""
+    mk = (lambda n: masks.get(n)) if masks else (lambda n: None)
     x = _conv_s(x, *p["initial_conv"])
     trunk = x
     for b in range(num_rrdb):
@@ -149,7 +160,7 @@ def generator_forward_t(p, x, scale, num_rrdb, attention=True):
             n = f"rrdb_{b}_dense{d}"
             feats = [x]
             for k in range(1, 5):
-                feats.append(_conv_s(torch.cat(feats, dim=1), *p[f"{n}_conv{k}"], act="relu"))
+                feats.append(_conv_s(torch.cat(feats, dim=1), *p[f"{n}_conv{k}"], act="relu", mask=mk(f"{n}_conv{k}")))
             x = x + 0.2 * _conv_s(torch.cat(feats, dim=1), *p[f"{n}_conv5"])
         x = r_in + 0.2 * x
     x = trunk + _conv_s(x, *p["trunk_conv"])
@@ -157,12 +168,13 @@ def generator_forward_t(p, x, scale, num_rrdb, attention=True):
         x = _sa_t(p, x, "self_attention_trunk")
     i, s = 0, scale
     while s > 1:
-        x = F.leaky_relu(_d2s(_conv_s(x, *p[f"upsample_{i}_conv"]), 2), 0.2)
+        x = _d2s(_conv_s(x, *p[f"upsample_{i}_conv"]), 2)
+        x = _masked_act(x, "lrelu", mk(f"upsample_{i}_conv")) if mk(f"upsample_{i}_conv") is not None else F.leaky_relu(x, 0.2)
         if i == 0 and attention:
             x = _sa_t(p, x, "self_attention_upsample_0")
         s >>= 1
         i += 1
-    x = _conv_s(x, *p["final_conv1"], act="relu")
+    x = _conv_s(x, *p["final_conv1"], act="relu", mask=mk("final_conv1"))
     return _conv_s(x, *p["final_conv2"], act="tanh")
 
 
@@ -179,9 +191,9 @@ def _sn_inplace(w, u):
     return w, u
 
 
-def discriminator_forward_t(p, x):
+def discriminator_forward_t(p, x, masks=None):
     for i, st in enumerate([1, 2, 1, 2, 1, 2]):
-        x = _conv_s(x, *p[f"disc_conv{i + 1}"], act="lrelu", stride=st)
+        x = _conv_s(x, *p[f"disc_conv{i + 1}"], act="lrelu", stride=st, mask=(masks or {}).get(f"disc_conv{i + 1}"))
     g = x.mean(dim=(2, 3))
     g = F.leaky_relu(g @ p["disc_dense1"][0] + p["disc_dense1"][1], 0.2)
     return torch.sigmoid(g @ p["disc_output"][0] + p["disc_output"][1])
@@ -210,12 +222,15 @@ def _grads(p):
 
 
 def esrgan_train_step_ref(gw, dw, u, vw, lr_img, hr_img, scale, num_rrdb, attention=True, g_lr=1e-4, d_lr=1e-5, g_opt=None, d_opt=None,
-                          dy_override=None):
+                          dy_override=None, g_masks=None, fake_override=None, d_masks=None):
     """One _train_step.  gw / dw / vw: {layer: (kernel, bias)}; u: {layer: [1,Cout]}; images NHWC in [-1,1].
     -> dict(losses, g_grads, d_grads, gw, dw, u, g_opt, d_opt, dy, y) with the updated state (fp64).
     dy_override (NHWC) replaces d g_loss / d G(lr) in the generator's backward pass: the loss gradient has kinks (ReLU / max-pool /
     |.| in the loss networks) where two correct implementations that differ in the last bit of y may legitimately take different
-    branches, so a test checks dy itself away from those kinks and the generator's backward on one common dy."""
+    branches, so a test checks dy itself away from those kinks and the generator's backward on one common dy.
+    g_masks ({layer: bool NHWC array}): the generator's ReLU / LeakyReLU branches in ITS backward pass pinned to the ones another evaluation took;
+    fake_override (NHWC) / d_masks ({"real": {...}, "fake": {...}}): the same for the discriminator update -- its input G(lr) and its LeakyReLU branches."""
+    tm = lambda d: None if d is None else {n: torch.tensor(np.asarray(a)).permute(0, 3, 1, 2) for n, a in d.items()}
     f64 = lambda w: {n: (np.asarray(k, np.float64), np.asarray(b, np.float64)) for n, (k, b) in w.items()}
     gw, dw, vw = f64(gw), f64(dw), f64(vw)
     g_opt = g_opt or AdamRef(gw, g_lr)
@@ -225,14 +240,16 @@ def esrgan_train_step_ref(gw, dw, u, vw, lr_img, hr_img, scale, num_rrdb, attent
     # ---- discriminator update: D(real) with K1 = SN(K0), D(fake) with K2 = SN(K1); gradients add; Adam acts on K2
     with torch.no_grad():
         fake = generator_forward_t(_params(gw), x, scale, num_rrdb, attention)
+    if fake_override is not None:
+        fake = torch.tensor(np.asarray(fake_override, np.float64)).permute(0, 3, 1, 2)
     dw, u = _sn_inplace(dw, u)
     p1 = _params(dw)
-    d_real = discriminator_forward_t(p1, hr)
+    d_real = discriminator_forward_t(p1, hr, tm((d_masks or {}).get("real")))
     l_real = _bce(torch.ones_like(d_real), d_real)
     l_real.backward()
     dw, u = _sn_inplace(dw, u)
     p2 = _params(dw)
-    d_fake = discriminator_forward_t(p2, fake)
+    d_fake = discriminator_forward_t(p2, fake, tm((d_masks or {}).get("fake")))
     l_fake = _bce(torch.zeros_like(d_fake), d_fake)
     l_fake.backward()
     g1, g2 = _grads(p1), _grads(p2)
@@ -240,7 +257,7 @@ def esrgan_train_step_ref(gw, dw, u, vw, lr_img, hr_img, scale, num_rrdb, attent
     dw = d_opt.apply(dw, d_grads)
     # ---- generator update (third renormalisation of D)
     pg = _params(gw)
-    y = generator_forward_t(pg, x, scale, num_rrdb, attention)
+    y = generator_forward_t(pg, x, scale, num_rrdb, attention, masks=tm(g_masks))
     y.retain_grad()
     dw, u = _sn_inplace(dw, u)
     pd = {n: (torch.tensor(k), torch.tensor(b)) for n, (k, b) in dw.items()}

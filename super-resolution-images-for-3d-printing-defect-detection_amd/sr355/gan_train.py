@@ -37,6 +37,7 @@ class Tape:
     def __init__(self, ctx, weights, wgrad=True, devcache=None):
         self.ctx, self.w, self.wgrad = ctx, weights, wgrad
         self.ops, self.grads = [], {}
+        self.masks = None                                       # diagnostics: a dict here collects {layer: activation > 0} of every ReLU / LeakyReLU conv
         self.dev = devcache if devcache is not None else {}     # id(host array) -> (host array, device tensor): one upload per array
 
     def _dev(self, a):
@@ -65,6 +66,8 @@ class Tape:
         k, b = kernel if kernel is not None else self.w[name]
         kd = self._dev(k)
         y = Var(ctx.conv2d_dev(x.v, kd, self._dev(b), k.shape[3], act=act, d2s=d2s))
+        if self.masks is not None and act in ("relu", "lrelu"):
+            self.masks[name] = y.v > 0
 
         def bwd():
             if y.g is None:
@@ -445,16 +448,24 @@ class ESRGANTrainer:
         # The reference runs the generator twice per step, once under each tape (ESRGAN_model.py:490, :508); its weights do not change
         # in between (the discriminator is updated first), so both runs are the same tensor: one taped forward serves both.
         tg = Tape(ctx, self._gw, devcache=devc)
+        collect = getattr(self, "collect_masks", False)           # tests: the activation branches of this step's forward passes (oracle/train.py _masked_act)
+        self.last_masks = {"g": {}, "d_real": {}, "d_fake": {}} if collect else None
+        if collect:
+            tg.masks = self.last_masks["g"]
         y = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att)
         fake = y.v
         # ---- discriminator update
         td = Tape(ctx, self.dw, devcache=devc)
+        if collect:
+            td.masks = self.last_masks["d_real"]
         p_real, seed_real = discriminator_forward(td, Var(hr_t, need=False), True, self.u)       # renormalisation 1
         l_real, dp = bce_mean(np.ones_like(p_real), p_real)
         seed_real(dp)
         td.backward()
         g_real = self._host(td.grads)
         td2 = Tape(ctx, self.dw, devcache=devc)
+        if collect:
+            td2.masks = self.last_masks["d_fake"]
         p_fake, seed_fake = discriminator_forward(td2, Var(fake, need=False), True, self.u)      # renormalisation 2
         l_fake, dp = bce_mean(np.zeros_like(p_fake), p_fake)
         seed_fake(dp)
@@ -501,5 +512,6 @@ class ESRGANTrainer:
         self._g_host_stale = True
         self.step += 1
         self._last = {"g_flat": g_flat, "g_names": set(tg.grads), "d": d_grads}
+        self.last_fake = fake
         return {"g_loss": adv + 1.0 * perc + 100.0 * pix + 1.0 * spec, "d_loss": l_real + l_fake, "adversarial": adv, "perceptual": perc,
                 "pixel": pix, "spectral": spec}

@@ -326,23 +326,44 @@ def test_esrgan_train_step_at_the_baseline_configuration(ctx):
     assert all(np.array_equal(runs[0][1][n], runs[1][1][n]) for n in runs[0][1]) and np.array_equal(runs[0][2], runs[1][2]) and np.array_equal(runs[0][3], runs[1][3])   # ... gradients, weights
     # ---- the oracle at this depth, on two of the patches
     tr = GT.ESRGANTrainer(ctx, gw, dw, vw, scale, nb, attention=True, g_lr=1e-4, d_lr=1e-5, u_seed=3)
+    tr.collect_masks = True
     u0 = {n: v.copy() for n, v in tr.u.items()}
     out = tr.train_step(lr[:2], hr[:2])
     dy = tr.last_dy.cpu().numpy().astype(np.float64)
-    ref = OT.esrgan_train_step_ref(gw, dw, u0, vw, lr[:2], hr[:2], scale, nb, attention=True, dy_override=dy)
+    host = lambda d: {n: m.cpu().numpy() for n, m in d.items()}
+
+    def dhost(d):
+        # the device runs a stride-2 layer as the stride-1 conv + LeakyReLU sampled at every second position (offset 1 for even sizes, 0 for odd:
+        # SURVEY.md A.1); the oracle convolves with stride 2 -- its mask is the sampled one
+        out_ = {}
+        for i, st in enumerate(GT.DISC_STRIDES):
+            m = d[f"disc_conv{i + 1}"].cpu().numpy()
+            if st == 2:
+                m = m[:, (0 if m.shape[1] % 2 else 1)::2, (0 if m.shape[2] % 2 else 1)::2]
+            out_[f"disc_conv{i + 1}"] = m
+        return out_
+    # The device's forward passes are fp32, the oracle's fp64: at the few elements whose pre-activation lies within the forward rounding error of zero
+    # the two take different ReLU / LeakyReLU branches, and one flipped activation in 1.2 M moves a gradient by ~1e-3 (round 3 widened the bounds to 5e-3
+    # on that argument).  Here the argument is tested instead: the oracle runs with the DEVICE's branches (oracle/train.py _masked_act) and, for the
+    # discriminator update, with the device's G(lr) -- what is left is arithmetic, and the bound is 5e-4 again.
+    ref = OT.esrgan_train_step_ref(gw, dw, u0, vw, lr[:2], hr[:2], scale, nb, attention=True, dy_override=dy, g_masks=host(tr.last_masks["g"]),
+                                   fake_override=tr.last_fake.cpu().numpy(), d_masks={"real": dhost(tr.last_masks["d_real"]), "fake": dhost(tr.last_masks["d_fake"])})
+    assert len(tr.last_masks["g"]) == 23 * 3 * 4 + 2 + 1 and len(tr.last_masks["d_real"]) == 6
     for k, v in ref["losses"].items():
         assert abs(out[k] - v) <= 5e-4 * max(1.0, abs(v)), (k, out[k], v)
-    # fp32 on the device against fp64.  final_conv2's gradient has no kink between it and dy (tanh): tight.  Every layer below final_conv1
-    # sees the ReLU / LeakyReLU masks of the DEVICE's forward pass, which at this depth differ from the fp64 graph's at the handful of
-    # pixels whose pre-activation is within the forward rounding error of zero: measured 1.5e-3 right below final_conv1 and 2.1-2.3e-3
-    # from there down to initial_conv -- it does not grow through the 351 convs, which is the property checked here.
     errs = {n: rel_l2(tr.last_grads["g"][n][0], ref["g_grads"][n][0])
             for n in ("final_conv2", "upsample_1_conv", "trunk_conv", "rrdb_22_dense3_conv5", "rrdb_11_dense2_conv3", "rrdb_0_dense1_conv1", "initial_conv")}
+    print("\ngenerator gradient rel-L2 vs the fp64 oracle on the device's branches:", {n: f"{e:.1e}" for n, e in errs.items()})
     assert errs["final_conv2"] <= 2e-4, errs
-    assert max(errs.values()) <= 5e-3 and errs["initial_conv"] <= 2.0 * errs["upsample_1_conv"] + 1e-3, errs
-    # the discriminator's gradients hang on G(lr) of the device (fp32 through 23 RRDBs) and its LeakyReLU masks: the same kink effect
+    assert max(errs.values()) <= 5e-4, errs
     derrs = {n: rel_l2(tr.last_grads["d"][n][0], rk) for n, (rk, rb) in ref["d_grads"].items()}
-    assert max(derrs.values()) <= 5e-3, derrs
+    print("discriminator gradient rel-L2:", {n: f"{e:.1e}" for n, e in derrs.items()})
+    assert max(derrs.values()) <= 5e-4, derrs
+    # and the premise, measured: with its OWN branches the fp64 oracle differs from the device in a handful of activations
+    ref_own = OT.esrgan_train_step_ref(gw, dw, u0, vw, lr[:2], hr[:2], scale, nb, attention=True, dy_override=dy)
+    own = rel_l2(tr.last_grads["g"]["initial_conv"][0], ref_own["g_grads"]["initial_conv"][0])
+    print(f"initial_conv gradient against the oracle on its own branches: {own:.1e}")
+    assert own <= 5e-3
 
 
 def test_esrgan_fit_wrapper(ctx, tmp_path):
