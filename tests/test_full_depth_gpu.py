@@ -60,9 +60,9 @@ def device_trace(ctx, dtype, w, x, nb=NB, stages=STAGES):
     else:
         # a tap on final_conv1 makes final_conv1 / final_conv2 run as two kernels: the activation is stored as ONE bf16 value; the untapped
         # forward folds the RGB conv into final_conv1's epilogue, where the never-stored activation enters as a bf16 hi + lo pair (round 4),
-        # so the two bf16 images differ by that one rounding of a 64-channel tensor: a flipped output rounding in a fraction of the pixels ...
+        # so the two bf16 images differ by that one rounding of a 64-channel tensor: output roundings flipped by an ulp (2^-8 at most on [-1, 1]) ...
         d = (y.float() - y2.float()).abs()
-        assert float(d.max()) <= 2.0 ** -6 and float((d > 0).float().mean()) < 0.25, (float(d.max()), float((d > 0).float().mean()))
+        assert float(d.max()) <= 2.0 ** -6 and float(d.mean()) <= 2.0 ** -9, (float(d.max()), float(d.mean()), float((d > 0).float().mean()))
         ctx.set_fused(ctx.FUSED_ALL & ~4, 0)                 # ... and are the same image when that pair runs as two kernels in both
         try:
             assert torch.equal(y, m.forward(ctx.to_device(x, td)))
