@@ -401,6 +401,8 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     // of stages -- one weight fragment x three column groups each -- and the fragment of stage k + WDEPTH is requested before the
     // MFMAs of stage k; a sched_barrier after every stage keeps the compiler from undoing the distance.  The next row's pixel
     // fragments are requested at the first stage of the current row, as before.
+    // (round 4, same-box A/B/A of the tail at 7056 patches: s_setprio 2 on the compute waves 1186.7 against 1186.6 / 1183.2 TFLOP/s, WDEPTH 4 1180.8, one
+    //  sched_barrier per two stages 1181.2: nothing moves it -- profiles/r04_dense_variants_ab.txt)
     constexpr int WDEPTH = 3, NWREG = WDEPTH + 1;
     // one (chunk, kx) granule on an external chunk staged at `sb`: staged row j holds stream row 8s-2+j; layer 0 (row 8s+w) reads
     // j = w+1+ky, layer 1 (row 8s+w-1) reads j = w+ky.  Stage order: row d = 0..3: [layer 0, ky = d-1 (d >= 1)] [layer 1, ky = d (d <= 2)]
