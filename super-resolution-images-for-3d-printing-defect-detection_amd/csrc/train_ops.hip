@@ -70,7 +70,110 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
     for (int e = threadIdx.x; e < 1024; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
-__global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit, int Cin, int Cout, int nci, int nco, float* dw) {
+// 3x3 layers, LDS-tiled (round 4).  The per-tap kernel above feeds every MFMA from two 4-byte global loads per lane and runs at their latency (56 us for the
+// 2 GFLOP of a dense block's conv5: 23 % of the fp32 peak; three variants of it -- two batches in flight, more pixel slices, nine taps per workgroup with
+// address arithmetic per load -- measured slower).  Here a workgroup owns an (input block, cout block) pair and a run of 8 x 24-pixel image tiles: the x tile with
+// its halo (10 x 26 pixels x 32 channels) and the dy tile (192 pixels x 32 couts) are staged into LDS with 16-byte loads, and every dy value meets the NINE shifted x
+// values of its pixel in nine accumulator tiles -- ten conflict-free ds_read_b32 per nine MFMAs.  The four waves interleave the tile's pixel pairs; their nine
+// tiles are summed through LDS in wave order, the runs of tiles (pixel splits) in wgrad_finish_kernel in split order: deterministic, no atomics.
+constexpr int WT_H = 8, WT_W = 24, WT_PW = WT_W + 2, WT_PH = WT_H + 2, WT_NPIX = WT_H * WT_W;
+
+__global__ void __launch_bounds__(256) wgrad3_tile_kernel(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int nci, int nco, int tiles_per_wg,
+                                                          int tilesX, int tilesY, float* partial, double* bpart) {
+    __shared__ __attribute__((aligned(16))) float xt[WT_PH * WT_PW * 32];
+    __shared__ __attribute__((aligned(16))) float dt[WT_NPIX * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, k = lane >> 5;
+    const int cob = blockIdx.x % nco, cib = blockIdx.x / nco;
+    const int ci0 = cib * 32, co0 = cob * 32;
+    const int ntile = B * tilesY * tilesX;
+    const int t0 = blockIdx.y * tiles_per_wg, t1 = min(ntile, t0 + tiles_per_wg);
+    const bool vec_x = (Cin & 3) == 0, vec_y = (Cout & 3) == 0;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const bool do_b = bpart != nullptr && cib == 0;
+    double bsum = 0.0;                                             // threads < 256: cout tid & 31, pixel group tid >> 5
+    for (int tile = t0; tile < t1; ++tile) {
+        int tt = tile;
+        const int tx = tt % tilesX; tt /= tilesX;
+        const int ty = tt % tilesY;
+        const int b = tt / tilesY;
+        const int y0 = ty * WT_H, x0 = tx * WT_W;
+        __syncthreads();                                           // the previous tile's operands have been read
+        for (int u = tid; u < WT_PH * WT_PW * 8; u += 256) {
+            const int pix = u >> 3, sl = u & 7;
+            const int py = pix / WT_PW, px = pix - py * WT_PW;
+            const int gy = y0 + py - 1, gx = x0 + px - 1, c = ci0 + sl * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
+                const float* src = x + (((int64_t)b * H + gy) * W + gx) * Cin + c;
+                if (vec_x) v = *reinterpret_cast<const f32x4*>(src);
+                else
+                    for (int e = 0; e < 4; ++e) v[e] = c + e < Cin ? src[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(xt + pix * 32 + sl * 4) = v;
+        }
+        for (int u = tid; u < WT_NPIX * 8; u += 256) {
+            const int pix = u >> 3, sl = u & 7;
+            const int py = pix / WT_W, px = pix - py * WT_W;
+            const int gy = y0 + py, gx = x0 + px, c = co0 + sl * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy < H && gx < W && c < Cout) {
+                const float* src = dy + (((int64_t)b * H + gy) * W + gx) * Cout + c;
+                if (vec_y) v = *reinterpret_cast<const f32x4*>(src);
+                else
+                    for (int e = 0; e < 4; ++e) v[e] = c + e < Cout ? src[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(dt + pix * 32 + sl * 4) = v;
+        }
+        __syncthreads();
+        if (do_b) {
+            const int co = tid & 31;
+            for (int p = tid >> 5; p < WT_NPIX; p += 8) bsum += (double)dt[p * 32 + co];
+        }
+        for (int kk = wave; kk < WT_NPIX / 2; kk += 4) {
+            const int p = 2 * kk + k;                              // this lane's pixel of the pair (24 is even: both in one row)
+            const int py = p / WT_W, px = p - py * WT_W;
+            const float bv = dt[p * 32 + i];
+            const float* xb = xt + (py * WT_PW + px) * 32 + i;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[(ky * WT_PW + kx) * 32], bv, acc[ky * 3 + kx], 0, 0, 0);
+        }
+    }
+    float* red = xt;                                               // 4 x 1024 floats: the x tile's space (16 of its 33 KiB)
+    static_assert(WT_PH * WT_PW * 32 >= 4 * 1024, "reduction fits the x tile");
+    const int ntiles_out = 9 * nci * nco;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * k;        // C/D layout of the 32x32 MFMA: col = lane & 31, row from the register index
+            red[wave * 1024 + row * 32 + i] = acc[t][e];
+        }
+        __syncthreads();
+        float* out = partial + (((size_t)blockIdx.y * ntiles_out + (t * nci + cib) * nco + cob) * 1024);
+        for (int e = tid; e < 1024; e += 256) out[e] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+    }
+    if (do_b) {
+        __syncthreads();
+        double* bred = reinterpret_cast<double*>(dt);              // [8][32] doubles
+        bred[(tid >> 5) * 32 + (tid & 31)] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            double t2 = 0.0;
+            for (int j = 0; j < 8; ++j) t2 += bred[j * 32 + tid];
+            bpart[((size_t)blockIdx.y * nco + cob) * 32 + tid] = t2;
+        }
+    }
+}
+
+__global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit, int Cin, int Cout, int nci, int nco, float* dw, const double* bpart, float* db) {
     // one thread per element of one 32x32 tile; dw is HWIO [tap][Cin][Cout]
     const int tile = blockIdx.x;
     int t = tile;
@@ -81,8 +184,14 @@ __global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit
         const int ci = cib * 32 + e / 32, co = cob * 32 + (e & 31);
         if (ci >= Cin || co >= Cout) continue;
         float s = 0.f;
+#pragma unroll 8
         for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * ntiles + tile) * 1024 + e];
         dw[((size_t)tap * Cin + ci) * Cout + co] = s;
+    }
+    if (bpart && db && tap == 0 && cib == 0 && threadIdx.x < 32 && cob * 32 + (int)threadIdx.x < Cout) {      // the tiled kernel's bias-gradient partials
+        double t2 = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) t2 += bpart[((size_t)sp * nco + cob) * 32 + threadIdx.x];
+        db[cob * 32 + threadIdx.x] = (float)t2;
     }
 }
 
@@ -315,13 +424,31 @@ int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int
     if (KS < 1 || !(KS & 1) || KS > 15) return ctx->fail(SR_ERR_INVALID, "wgrad: odd kernel sizes up to 15 only");
     const int nci = (Cin + 31) / 32, nco = (Cout + 31) / 32, ntiles = KS * KS * nci * nco;
     const int64_t P = (int64_t)B * H * W;
+    static const bool per_tap = getenv("SR355_WGRAD_PER_TAP") != nullptr;       // A/B switch (diagnostic): round 3's kernel for every layer
+    if (KS == 3 && !per_tap) {
+        const int tilesX = (W + WT_W - 1) / WT_W, tilesY = (H + WT_H - 1) / WT_H, ntile = B * tilesY * tilesX;
+        // pixel splits: enough workgroups for ~1.5 per CU, each a whole number of 8 x 24 tiles
+        int nsplit = (3 * ctx->cu_count() / 2 + nci * nco - 1) / (nci * nco);
+        if (nsplit > ntile) nsplit = ntile;
+        if (nsplit > 64) nsplit = 64;
+        const int tiles_per_wg = (ntile + nsplit - 1) / nsplit;
+        nsplit = (ntile + tiles_per_wg - 1) / tiles_per_wg;
+        const size_t tile_bytes = (size_t)nsplit * ntiles * 1024 * sizeof(float);
+        float* partial = static_cast<float*>(ctx->scratch(tile_bytes + (size_t)nsplit * nco * 32 * sizeof(double)));
+        if (!partial) return SR_ERR_OOM;
+        double* bpart = db ? reinterpret_cast<double*>(reinterpret_cast<char*>(partial) + tile_bytes) : nullptr;
+        hipLaunchKernelGGL(wgrad3_tile_kernel, dim3(nci * nco, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, nci, nco, tiles_per_wg, tilesX, tilesY, partial, bpart);
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, bpart, db);
+        SR_HIP(ctx, hipGetLastError());
+        return SR_OK;
+    }
     int nsplit = (int)((P + WG_SPLIT_PIX - 1) / WG_SPLIT_PIX);
     if (nsplit > 64) nsplit = 64;
     if (nsplit < 1) nsplit = 1;
     float* partial = static_cast<float*>(ctx->scratch((size_t)nsplit * ntiles * 1024 * sizeof(float)));
     if (!partial) return SR_ERR_OOM;
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial);
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, (const double*)nullptr, (float*)nullptr);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(Cout), dim3(256), 0, st, dy, P, Cout, db);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
