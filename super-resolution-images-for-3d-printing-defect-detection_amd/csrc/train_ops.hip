@@ -184,12 +184,13 @@ __global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit
         const int ci = cib * 32 + e / 32, co = cob * 32 + (e & 31);
         if (ci >= Cin || co >= Cout) continue;
         float s = 0.f;
-#pragma unroll 8
-        for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * ntiles + tile) * 1024 + e];
+#pragma unroll 16
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * ntiles + tile) * 1024 + e];      // (unrolled: the loads of 16 splits in flight at once)
         dw[((size_t)tap * Cin + ci) * Cout + co] = s;
     }
     if (bpart && db && tap == 0 && cib == 0 && threadIdx.x < 32 && cob * 32 + (int)threadIdx.x < Cout) {      // the tiled kernel's bias-gradient partials
         double t2 = 0.0;
+#pragma unroll 16
         for (int sp = 0; sp < nsplit; ++sp) t2 += bpart[((size_t)sp * nco + cob) * 32 + threadIdx.x];
         db[cob * 32 + threadIdx.x] = (float)t2;
     }
