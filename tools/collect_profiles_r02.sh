@@ -29,6 +29,9 @@ for t in 2 4 8 16; do
   python3 bench.py --tiles $t --tiles-per-call $t --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-profile --no-rows 2>/dev/null | tail -1 >> "$OUT/${TAG}_tiles_sweep.jsonl" || echo "tiles $t failed"
 done
 echo "tiles sweep done"
+# DVFS diagnostic (MI355X_MICROARCH.md "DVFS give-back" item 1): the same launches on all-zero weights and tiles -- what the kernels' times become when no operand bit toggles
+python3 bench.py --zero-data --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_zero_data.json" || echo "zero-data run failed"
+echo "zero-data run done"
 rm -rf "$OUT/bench" ; find "$OUT/pmc_fetch" "$OUT/pmc_write" -name "*.csv" -size +8M -delete
 cat "$OUT/pmc_traffic.log"; head -6 "$OUT/${TAG}_bench_kernel_stats.csv"; cut -c1-300 "$OUT/${TAG}_bench.json"; python3 -c "
 import json
