@@ -207,6 +207,16 @@ int  sr_conv2d_wgrad(sr_ctx* ctx, const void* x, const void* dy, int B, int H, i
 int  sr_conv2d_dev(sr_ctx* ctx, const void* x, int B, int H, int W, int Cin, const float* d_w, const float* d_bias, int K, int Cout,
                    int rot, int act, float alpha, const void* skip1, float beta1, const void* skip2, float beta2, int clip01,
                    int d2s_r, void* y, void* stream);
+/* The same three pieces of the training step on CHANNEL RANGES of NHWC fp32 buffers (ESRGAN_model.py:212-254: a dense block's concat tensor kept in one buffer,
+ * every conv reading a prefix of it and writing its own slice; in the backward pass every input gradient accumulating in place into a prefix of the gradient
+ * buffer through skip1 = y).  sr_view: p = the buffer, cs = its channels per pixel, coff = the view's first channel (cs, coff multiples of 4; the conv's Cin a
+ * multiple of 16).  sr_eltwise_views: op over npix pixels x C channels. */
+typedef struct { const void* p; int64_t cs; int32_t coff; } sr_view;
+int  sr_conv2d_dev_views(sr_ctx* ctx, const sr_view* x, int B, int H, int W, int Cin, const float* d_w, const float* d_bias, int K, int Cout, int rot,
+                         int act, float alpha, const sr_view* skip1, float beta1, const sr_view* y, void* stream);
+int  sr_conv2d_wgrad_views(sr_ctx* ctx, const sr_view* x, const sr_view* dy, int B, int H, int W, int Cin, int Cout, int K,
+                           float* dw_hwio, float* db, void* stream);
+int  sr_eltwise_views(sr_ctx* ctx, int op, const sr_view* a, const sr_view* b, float alpha, float beta, const sr_view* out, int64_t npix, int C, void* stream);
 int  sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, float beta, void* out, int64_t n, void* stream);
 /* keras.optimizers.Adam's dense update (the optimiser of ESRGAN_model.py:176-195, SRCNN_model.py:55-60, EDSR_model.py:127-140) over one flat
  * fp32 bucket of n parameters, in place on the device: g is first multiplied by grad_scale (1 / world size after a summing all-reduce; 1 leaves

@@ -1115,6 +1115,49 @@ int sr_conv2d_dev(sr_ctx* ctx, const void* x, int B, int H, int W, int Cin, cons
     return conv_launch(ctx, cw, TensorView{xp, Cp, 0}, B, H, W, y, Cout / (r * r), 0, ep, st);
 }
 
+// The training tape's dense blocks keep their concat tensor [B, H, W, 64 + 4 G] in ONE buffer: every conv reads a channel prefix of it and writes its
+// own slice (forward), every input gradient accumulates into a prefix of the gradient buffer in place (backward) -- no concat copies, no slice copies, no
+// separate accumulate launches (round 3: ~30 of them per dense block).  A view = (pointer, channels per pixel of the buffer, first channel).
+int sr_conv2d_dev_views(sr_ctx* ctx, const sr_view* x, int B, int H, int W, int Cin, const float* d_w, const float* d_bias, int K, int Cout, int rot, int act, float alpha,
+                        const sr_view* skip1, float beta1, const sr_view* y, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!x || !x->p || !d_w || !y || !y->p) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ctx->fail(SR_ERR_INVALID, "bad tensor shape");
+    for (const sr_view* v : {x, y, skip1})
+        if (v && v->p && (v->coff < 0 || v->cs <= 0 || v->coff >= v->cs)) return ctx->fail(SR_ERR_INVALID, "bad view");
+    if (x->cs - x->coff < Cin || y->cs - y->coff < Cout || (skip1 && skip1->p && skip1->cs - skip1->coff < Cout)) return ctx->fail(SR_ERR_INVALID, "a view is narrower than its channel count");
+    ConvWeights cw;
+    int rc = conv_pack_weights_dev(ctx, d_w, d_bias, K, Cin, Cout, rot, &cw, st);
+    if (rc) return rc;
+    if (cw.thin || cw.CinP != Cin) return ctx->fail(SR_ERR_INVALID, "conv views: the input channel count must be a whole number of the kernel's channel chunks (16 fp32 channels)");
+    ConvEpilogue ep;
+    ep.act = act; ep.alpha = alpha;
+    if (skip1 && skip1->p) { ep.skip1 = {skip1->p, skip1->cs, skip1->coff}; ep.beta1 = beta1; }
+    return conv_launch(ctx, cw, TensorView{x->p, x->cs, x->coff}, B, H, W, TensorView{y->p, y->cs, y->coff}, ep, st);
+}
+
+int sr_conv2d_wgrad_views(sr_ctx* ctx, const sr_view* x, const sr_view* dy, int B, int H, int W, int Cin, int Cout, int K, float* dw_hwio, float* db, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!x || !x->p || !dy || !dy->p || !dw_hwio) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    if (x->coff < 0 || dy->coff < 0 || x->cs - x->coff < Cin || dy->cs - dy->coff < Cout) return ctx->fail(SR_ERR_INVALID, "a view is narrower than its channel count");
+    return wgrad_launch_views(ctx, static_cast<const float*>(x->p) + x->coff, x->cs, static_cast<const float*>(dy->p) + dy->coff, dy->cs, B, H, W, Cin, Cout, K, dw_hwio, db,
+                              static_cast<hipStream_t>(stream));
+}
+
+int sr_eltwise_views(sr_ctx* ctx, int op, const sr_view* a, const sr_view* b, float alpha, float beta, const sr_view* out, int64_t npix, int C, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (!a || !a->p || !out || !out->p) return ctx->fail(SR_ERR_INVALID, "null tensor");
+    for (const sr_view* v : {a, b, out})
+        if (v && v->p && (v->coff < 0 || v->cs - v->coff < C)) return ctx->fail(SR_ERR_INVALID, "a view is narrower than its channel count");
+    const float* bp = (b && b->p) ? static_cast<const float*>(b->p) + b->coff : nullptr;
+    return eltwise_views_launch(ctx, op, static_cast<const float*>(a->p) + a->coff, a->cs, bp, bp ? b->cs : 0, alpha, beta,
+                                static_cast<float*>(const_cast<void*>(out->p)) + out->coff, out->cs, npix, C, static_cast<hipStream_t>(stream));
+}
+
 int sr_self_attention(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int C, const float* wf, const float* bf, const float* wg,
                       const float* bg, const float* wh, const float* bh, const float* wv, const float* bv, void* y, void* stream) {
     DeviceGuard dg_(ctx);

@@ -242,6 +242,10 @@ int vgg_preproc_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, v
 int l1_launch(sr_ctx* ctx, const float* a, const float* b, int64_t n, float* out, hipStream_t st);
 int spectral_l1_launch(sr_ctx* ctx, const float* a, const float* b, int B, int H, int W, int C, float* out, hipStream_t st);
 int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS, float* dw, float* db, hipStream_t st);
+int wgrad_launch_views(sr_ctx* ctx, const float* x, int64_t x_cs, const float* dy, int64_t dy_cs, int B, int H, int W, int Cin, int Cout, int KS, float* dw, float* db,
+                       hipStream_t st);
+int eltwise_views_launch(sr_ctx* ctx, int op, const float* a, int64_t a_cs, const float* b, int64_t b_cs, float alpha, float beta, float* out, int64_t o_cs, int64_t npix, int C,
+                         hipStream_t st);
 int adam_launch(sr_ctx* ctx, float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float omb1, float b2, float omb2, float eps,
                 float gscale, hipStream_t st);
 int eltwise_launch(sr_ctx* ctx, int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n, hipStream_t st);

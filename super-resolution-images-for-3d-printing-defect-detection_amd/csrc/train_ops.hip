@@ -78,8 +78,10 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* x, cons
 // tiles are summed through LDS in wave order, the runs of tiles (pixel splits) in wgrad_finish_kernel in split order: deterministic, no atomics.
 constexpr int WT_H = 8, WT_W = 24, WT_PW = WT_W + 2, WT_PH = WT_H + 2, WT_NPIX = WT_H * WT_W;
 
-__global__ void __launch_bounds__(256) wgrad3_tile_kernel(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int nci, int nco, int tiles_per_wg,
-                                                          int tilesX, int tilesY, float* partial, double* bpart) {
+__global__ void __launch_bounds__(256) wgrad3_tile_kernel(const float* x, int64_t x_cs, const float* dy, int64_t dy_cs, int B, int H, int W, int Cin, int Cout, int nci, int nco,
+                                                          int tiles_per_wg, int tilesX, int tilesY, float* partial, double* bpart) {
+    // x / dy: NHWC views -- x_cs / dy_cs channels per pixel in the underlying buffer, the pointers already at the view's first channel (round 4: the
+    // trainer's dense blocks keep their concat tensor in ONE buffer and hand every conv a channel range of it)
     __shared__ __attribute__((aligned(16))) float xt[WT_PH * WT_PW * 32];
     __shared__ __attribute__((aligned(16))) float dt[WT_NPIX * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, k = lane >> 5;
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256) wgrad3_tile_kernel(const float* x, const 
     const int ci0 = cib * 32, co0 = cob * 32;
     const int ntile = B * tilesY * tilesX;
     const int t0 = blockIdx.y * tiles_per_wg, t1 = min(ntile, t0 + tiles_per_wg);
-    const bool vec_x = (Cin & 3) == 0, vec_y = (Cout & 3) == 0;
+    const bool vec_x = (Cin & 3) == 0 && (x_cs & 3) == 0 && ((uintptr_t)x & 15) == 0, vec_y = (Cout & 3) == 0 && (dy_cs & 3) == 0 && ((uintptr_t)dy & 15) == 0;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(256) wgrad3_tile_kernel(const float* x, const 
             const int gy = y0 + py - 1, gx = x0 + px - 1, c = ci0 + sl * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
-                const float* src = x + (((int64_t)b * H + gy) * W + gx) * Cin + c;
+                const float* src = x + (((int64_t)b * H + gy) * W + gx) * x_cs + c;
                 if (vec_x) v = *reinterpret_cast<const f32x4*>(src);
                 else
                     for (int e = 0; e < 4; ++e) v[e] = c + e < Cin ? src[e] : 0.f;
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(256) wgrad3_tile_kernel(const float* x, const 
             const int gy = y0 + py, gx = x0 + px, c = co0 + sl * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gy < H && gx < W && c < Cout) {
-                const float* src = dy + (((int64_t)b * H + gy) * W + gx) * Cout + c;
+                const float* src = dy + (((int64_t)b * H + gy) * W + gx) * dy_cs + c;
                 if (vec_y) v = *reinterpret_cast<const f32x4*>(src);
                 else
                     for (int e = 0; e < 4; ++e) v[e] = c + e < Cout ? src[e] : 0.f;
@@ -205,6 +207,30 @@ __global__ void colsum_kernel(const float* dy, int64_t P, int C, float* out) {
     __syncthreads();
     for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) out[c] = (float)red[0];
+}
+
+__device__ __forceinline__ float eltwise_value(int op, float av, float bv, float alpha, float beta) {
+    switch (op) {
+        case SR_ELT_AXPBY: return alpha * av + beta * bv;
+        case SR_ELT_RELU_BWD: return bv > 0.f ? av : 0.f;
+        case SR_ELT_LRELU_BWD: return bv > 0.f ? av : 0.2f * av;
+        case SR_ELT_CLIP01_BWD: return (bv >= 0.f && bv <= 1.f) ? av : 0.f;
+        case SR_ELT_MUL: return alpha * av * bv;
+        case SR_ELT_TANH_BWD: return av * (1.f - bv * bv);
+        case SR_ELT_CLIP01: return fminf(fmaxf(av, 0.f), 1.f);
+        case SR_ELT_SIGN_DIFF: return alpha * (av > bv ? 1.f : (av < bv ? -1.f : 0.f));
+        default: return 0.f;
+    }
+}
+
+// the same ops on channel ranges of NHWC buffers: element (pixel p, channel c) of a view lives at p * cs + c from the view's pointer
+__global__ void eltwise_view_kernel(int op, const float* a, int64_t a_cs, const float* b, int64_t b_cs, float alpha, float beta, float* out, int64_t o_cs, int64_t npix, int C) {
+    const int64_t n = npix * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C;
+        const int c = (int)(i - p * C);
+        out[p * o_cs + c] = eltwise_value(op, a[p * a_cs + c], b ? b[p * b_cs + c] : 0.f, alpha, beta);
+    }
 }
 
 __global__ void eltwise_kernel(int op, const float* a, const float* b, float alpha, float beta, float* out, int64_t n) {
@@ -421,11 +447,30 @@ unsigned grid_n(int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g < 
 }  // namespace
 
 int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, int KS, float* dw, float* db, hipStream_t st) {
+    return wgrad_launch_views(ctx, x, Cin, dy, Cout, B, H, W, Cin, Cout, KS, dw, db, st);
+}
+
+int eltwise_views_launch(sr_ctx* ctx, int op, const float* a, int64_t a_cs, const float* b, int64_t b_cs, float alpha, float beta, float* out, int64_t o_cs, int64_t npix, int C,
+                         hipStream_t st) {
+    if (npix <= 0 || C <= 0) return SR_OK;
+    if (op < 0 || op > SR_ELT_SIGN_DIFF) return ctx->fail(SR_ERR_INVALID, "eltwise: unknown op");
+    if (op != SR_ELT_AXPBY && op != SR_ELT_CLIP01 && !b) return ctx->fail(SR_ERR_INVALID, "eltwise: this op needs two operands");
+    if (a_cs < C || o_cs < C || (b && b_cs < C)) return ctx->fail(SR_ERR_INVALID, "eltwise: a view is narrower than its channel count");
+    hipLaunchKernelGGL(eltwise_view_kernel, dim3(grid_n(npix * C)), dim3(256), 0, st, op, a, a_cs, b, b_cs, alpha, beta, out, o_cs, npix, C);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int wgrad_launch_views(sr_ctx* ctx, const float* x, int64_t x_cs, const float* dy, int64_t dy_cs, int B, int H, int W, int Cin, int Cout, int KS, float* dw, float* db,
+                       hipStream_t st) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ctx->fail(SR_ERR_INVALID, "wgrad: empty tensor");
+    if (x_cs < Cin || dy_cs < Cout) return ctx->fail(SR_ERR_INVALID, "wgrad: a view is narrower than its channel count");
+    if ((x_cs != Cin || dy_cs != Cout) && KS != 3) return ctx->fail(SR_ERR_INVALID, "wgrad: channel-range views are built for 3x3 layers");
     if (KS < 1 || !(KS & 1) || KS > 15) return ctx->fail(SR_ERR_INVALID, "wgrad: odd kernel sizes up to 15 only");
     const int nci = (Cin + 31) / 32, nco = (Cout + 31) / 32, ntiles = KS * KS * nci * nco;
     const int64_t P = (int64_t)B * H * W;
-    static const bool per_tap = getenv("SR355_WGRAD_PER_TAP") != nullptr;       // A/B switch (diagnostic): round 3's kernel for every layer
+    static const bool per_tap_env = getenv("SR355_WGRAD_PER_TAP") != nullptr;   // A/B switch (diagnostic): round 3's kernel for every layer (dense tensors only)
+    const bool per_tap = per_tap_env && x_cs == Cin && dy_cs == Cout;
     if (KS == 3 && !per_tap) {
         const int tilesX = (W + WT_W - 1) / WT_W, tilesY = (H + WT_H - 1) / WT_H, ntile = B * tilesY * tilesX;
         // pixel splits: enough workgroups for ~1.5 per CU, each a whole number of 8 x 24 tiles
@@ -438,7 +483,7 @@ int wgrad_launch(sr_ctx* ctx, const float* x, const float* dy, int B, int H, int
         float* partial = static_cast<float*>(ctx->scratch(tile_bytes + (size_t)nsplit * nco * 32 * sizeof(double)));
         if (!partial) return SR_ERR_OOM;
         double* bpart = db ? reinterpret_cast<double*>(reinterpret_cast<char*>(partial) + tile_bytes) : nullptr;
-        hipLaunchKernelGGL(wgrad3_tile_kernel, dim3(nci * nco, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, nci, nco, tiles_per_wg, tilesX, tilesY, partial, bpart);
+        hipLaunchKernelGGL(wgrad3_tile_kernel, dim3(nci * nco, nsplit), dim3(256), 0, st, x, x_cs, dy, dy_cs, B, H, W, Cin, Cout, nci, nco, tiles_per_wg, tilesX, tilesY, partial, bpart);
         hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, bpart, db);
         SR_HIP(ctx, hipGetLastError());
         return SR_OK;

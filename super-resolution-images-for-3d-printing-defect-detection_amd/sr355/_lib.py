@@ -26,7 +26,13 @@ class ModelCfg(C.Structure):
                 ("res_scaling", C.c_float), ("num_classes", C.c_int32), ("use_attention", C.c_int32)]
 
 
+class View(C.Structure):
+    """sr_view: a channel range of an NHWC fp32 buffer (include/sr355.h)."""
+    _fields_ = [("p", C.c_void_p), ("cs", C.c_int64), ("coff", C.c_int32)]
+
+
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+_vw = C.POINTER(View)
 _fp = C.POINTER(C.c_float)
 _i64p = C.POINTER(C.c_int64)
 
@@ -66,6 +72,9 @@ SIGNATURES = {
     "sr_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sr_conv2d_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _vp, _f, _i, _i, _vp, _vp]),
     "sr_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sr_conv2d_dev_views": (_i, [_vp, _vw, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vw, _f, _vw, _vp]),
+    "sr_conv2d_wgrad_views": (_i, [_vp, _vw, _vw, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sr_eltwise_views": (_i, [_vp, _i, _vw, _vw, _f, _f, _vw, _i64, _i, _vp]),
     "sr_eltwise": (_i, [_vp, _i, _vp, _vp, _f, _f, _vp, _i64, _vp]),
     "sr_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "sr_space_to_depth": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -105,6 +105,52 @@ class Tape:
         self.ops.append(bwd)
         return y
 
+    def dense_block(self, x, name, growth):
+        """ESRGAN._dense_block (ESRGAN_model.py:212-254) as ONE tape op on a virtual-concat buffer: F = [x | f1 | f2 | f3 | f4] lives in one
+        [B,H,W,64+4g] tensor, conv k reads its channel prefix and writes slice k (sr_conv2d_dev_views); returns x + 0.2 * conv5(F).  Backward: the
+        gradient of F is one buffer too -- conv5's input gradient fills it, every growth conv's accumulates into its prefix IN PLACE (skip = output
+        range), ReLU masks and weight gradients read their slices where they lie.  Round 3 built F by four torch.cat copies and took the gradient apart
+        by ~14 slice copies and as many accumulate launches per block."""
+        ctx = self.ctx
+        B, H, W, C0 = x.v.shape
+        g = int(growth)
+        Ct = C0 + 4 * g
+        F = ctx.empty((B, H, W, Ct))
+        ctx.eltwise_view(L.ELT_AXPBY, x.v, 0, None, 0, F, 0, C0, 1.0, 0.0)
+        ws = [self.w[f"{name}_conv{k}"] for k in range(1, 6)]
+        for k in range(1, 5):
+            kk, bb = ws[k - 1]
+            cin = C0 + (k - 1) * g
+            ctx.conv2d_dev_view(F, 0, cin, self._dev(kk), self._dev(bb), g, F, cin, act="relu")
+            if self.masks is not None:
+                self.masks[f"{name}_conv{k}"] = F[..., cin:cin + g] > 0
+        k5, b5 = ws[4]
+        y = Var(ctx.empty((B, H, W, C0)))
+        ctx.conv2d_dev_view(F, 0, Ct, self._dev(k5), self._dev(b5), C0, y.v, 0, alpha=0.2, skip_buf=F, skip_coff=0, beta1=1.0)      # x + 0.2 * conv5
+
+        def bwd():
+            if y.g is None:
+                return
+            G = ctx.empty((B, H, W, Ct))
+            dz5 = ctx.eltwise(L.ELT_AXPBY, y.g, None, 0.2, 0.0)
+            if self.wgrad:
+                self._pgrad(f"{name}_conv5", *ctx.conv2d_wgrad_view(F, 0, Ct, dz5, 0, C0, 3))
+            ctx.conv2d_dev_view(dz5, 0, C0, self._dev(k5), None, Ct, G, 0, rot=True)                        # fills every channel of G
+            dz = ctx.empty((B, H, W, g))
+            for k in range(4, 0, -1):
+                kk, _ = ws[k - 1]
+                cin = C0 + (k - 1) * g
+                ctx.eltwise_view(L.ELT_RELU_BWD, G, cin, F, cin, dz, 0, g)                                 # slice k of G is complete: convs k+1..5 have added to it
+                if self.wgrad:
+                    self._pgrad(f"{name}_conv{k}", *ctx.conv2d_wgrad_view(F, 0, cin, dz, 0, g, 3))
+                ctx.conv2d_dev_view(dz, 0, g, self._dev(kk), None, cin, G, 0, rot=True, skip_buf=G, skip_coff=0, beta1=1.0)   # G[..., :cin] += dgrad
+            if x.need:
+                dx = ctx.empty((B, H, W, C0))
+                ctx.eltwise_view(L.ELT_AXPBY, G, 0, y.g, 0, dx, 0, C0, 1.0, 1.0)                           # + the skip path's share
+                self._acc(x, dx)
+        self.ops.append(bwd)
+        return y
+
     def axpby(self, a, b, alpha, beta):
         y = Var(self.ctx.eltwise(L.ELT_AXPBY, a.v, b.v, alpha, beta))
 
@@ -165,6 +211,12 @@ class Tape:
 
 
 # ----------------------------------------------------------------------------------------------------------------- networks
+# dense blocks on one virtual-concat buffer per block (Tape.dense_block) where the growth width is a whole number of the fp32 conv's 16-channel chunks
+# (G = 32: yes; the notebook's G = 8: the cat path); SR355_TAPE_CAT=1 restores round 3's cat path for A/B runs
+import os as _os
+VIRTUAL_CONCAT = _os.environ.get("SR355_TAPE_CAT") is None
+
+
 def generator_forward(t, x, scale, num_rrdb, attention=True):
     """ESRGAN_model.py:303-345 on the tape; x Var [B,h,w,3] in [-1,1]."""
     x = t.conv(x, "initial_conv")
@@ -173,6 +225,10 @@ def generator_forward(t, x, scale, num_rrdb, attention=True):
         r_in = x
         for d in (1, 2, 3):
             n = f"rrdb_{b}_dense{d}"
+            growth = t.w[f"{n}_conv1"][0].shape[3]
+            if VIRTUAL_CONCAT and growth % 16 == 0:
+                x = t.dense_block(x, n, growth)
+                continue
             feats = [x]
             for k in range(1, 5):
                 feats.append(t.conv(t.cat(feats), f"{n}_conv{k}", act="relu"))

@@ -241,6 +241,49 @@ class Context:
         self.check(self.lib.sr_mse(self.h, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), self.stream()))
         return out
 
+    # ------------------------------------------------------------------ channel-range views (the training tape's dense blocks: sr_*_views)
+    @staticmethod
+    def _view(t, coff, c):
+        """(tensor [B,H,W,Cbuf] fp32 contiguous, first channel, channels) -> sr_view."""
+        if not (isinstance(t, torch.Tensor) and t.dim() == 4 and t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda):
+            raise ValueError("a view needs a contiguous fp32 NHWC device tensor")
+        if coff < 0 or c <= 0 or coff + c > t.shape[3]:
+            raise ValueError(f"channel range [{coff}, {coff + c}) outside the buffer's {t.shape[3]} channels")
+        return L.View(t.data_ptr(), int(t.shape[3]), int(coff))
+
+    def conv2d_dev_view(self, xbuf, x_coff, cin, w_dev, b_dev, cout, ybuf, y_coff, rot=False, act="linear", alpha=1.0, skip_buf=None, skip_coff=0, beta1=0.0):
+        """sr_conv2d_dev on channel ranges: reads xbuf[..., x_coff : x_coff + cin], writes ybuf[..., y_coff : y_coff + cout] (other channels untouched);
+        skip_buf / skip_coff: out = alpha * act(conv) + beta1 * skip -- skip may be the output range itself (in-place accumulation)."""
+        B, H, W, _ = xbuf.shape
+        if tuple(ybuf.shape[:3]) != (B, H, W):
+            raise ValueError("conv2d_dev_view: input and output buffers must share [B,H,W]")
+        k = w_dev.shape[0]
+        want = (k, k, cout, cin) if rot else (k, k, cin, cout)
+        if tuple(w_dev.shape) != want:
+            raise ValueError(f"conv2d_dev_view: kernel shape {tuple(w_dev.shape)} does not match {want}")
+        xv, yv = self._view(xbuf, x_coff, cin), self._view(ybuf, y_coff, cout)
+        sv = None if skip_buf is None else self._view(skip_buf, skip_coff, cout)
+        actc = {"linear": L.ACT_LINEAR, None: L.ACT_LINEAR, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH}[act]
+        self.check(self.lib.sr_conv2d_dev_views(self.h, C.byref(xv), B, H, W, int(cin), w_dev.data_ptr(), None if b_dev is None else b_dev.data_ptr(), k, int(cout),
+                                                int(bool(rot)), actc, float(alpha), None if sv is None else C.byref(sv), float(beta1), C.byref(yv), self.stream()))
+
+    def conv2d_wgrad_view(self, xbuf, x_coff, cin, dybuf, dy_coff, cout, k):
+        """sr_conv2d_wgrad on channel ranges -> (dw HWIO [k,k,cin,cout], db [cout]) device tensors."""
+        B, H, W, _ = xbuf.shape
+        xv, dv = self._view(xbuf, x_coff, cin), self._view(dybuf, dy_coff, cout)
+        dw = self.empty((k, k, cin, cout), torch.float32)
+        db = self.empty((cout,), torch.float32)
+        self.check(self.lib.sr_conv2d_wgrad_views(self.h, C.byref(xv), C.byref(dv), B, H, W, int(cin), int(cout), int(k), dw.data_ptr(), db.data_ptr(), self.stream()))
+        return dw, db
+
+    def eltwise_view(self, op, abuf, a_coff, bbuf, b_coff, obuf, o_coff, c, alpha=1.0, beta=0.0):
+        """sr_eltwise over c channels of every pixel: out range = op(a range, b range) (bbuf None for one-operand ops)."""
+        B, H, W, _ = abuf.shape
+        av, ov = self._view(abuf, a_coff, c), self._view(obuf, o_coff, c)
+        bv = None if bbuf is None else self._view(bbuf, b_coff, c)
+        self.check(self.lib.sr_eltwise_views(self.h, int(op), C.byref(av), None if bv is None else C.byref(bv), float(alpha), float(beta), C.byref(ov), B * H * W, int(c),
+                                             self.stream()))
+
     # ------------------------------------------------------------------ backward-pass pieces (sr355/train.py)
     def conv2d_wgrad(self, x, dy, k):
         """Kernel and bias gradient of Conv2D(k x k, SAME, stride 1): x [B,H,W,Cin], dy [B,H,W,Cout] fp32 -> (dw HWIO, db) device tensors."""
