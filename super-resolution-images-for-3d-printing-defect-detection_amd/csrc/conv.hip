@@ -551,22 +551,18 @@ inline uint16_t f32_to_bf16_host(float f) {
 // ---------------------------------------------------------------------------------------------
 template <int KS>
 __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
-    // Round 4: the multiply-adds run on the matrix core after all -- not on the 32-cout tile (ten times the work) but on v_mfma_f32_4x4x1_16B_f32: sixteen
-    // independent 4 x 4 x 1 blocks per instruction, here 4 couts x 4 pixels each, so a wave's 64 lanes are 64 pixels and a lane's four result registers its
-    // pixel's four couts (the VALU loop's acc[4]) -- 512 FLOP per 8-cycle instruction where four v_fma_f32 (16 cycles) did 512.  One k step = one (tap, input
-    // channel); the order (4-channel chunk, ky, kx, channel) is the VALU kernel's, each step one fused multiply-add per output: the same sums, bit for bit.
-    // A operand: weight (tap, ci) of cout lane & 3 -- the chunk's 25 x 4 x 4 floats staged as [tap][cout][ci] so that a lane's four ci are one ds_read_b128
-    // (lanes of one cout read one address: a broadcast).
     constexpr int TS = 16, PS = TS + KS - 1, PADK = (KS - 1) / 2;
     __shared__ __attribute__((aligned(16))) float tile[PS * PS * 4];
-    __shared__ __attribute__((aligned(16))) float wl[KS * KS * 16];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int b = blockIdx.z, y0 = blockIdx.y * TS, x0 = blockIdx.x * TS;
     const int H = p.H, W = p.W;
     const float* inb = reinterpret_cast<const float*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;
-    const float* __restrict__ wk = reinterpret_cast<const float*>(p.w);      // [tap][CinP][4]
+    const f32x4* __restrict__ wk = reinterpret_cast<const f32x4*>(p.w);
     const int CinP = p.nchunks * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // (round 4: the four couts as two v_pk_fma_f32 pairs -- pixel value broadcast by op_sel, weight pair in SGPRs, half the vector instructions -- measured
+    //  0.78 ms against 0.73 for 4 x 1024 x 1024; the same loop on v_mfma_f32_4x4x1 (64 pixels x 4 couts per instruction, bit-identical sums) 0.76: the kernel
+    //  is not bound by its arithmetic issue either way; both reverted)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c4 = 0; c4 < p.nchunks; ++c4) {
         __syncthreads();
         for (int u = tid; u < PS * PS; u += 256) {
@@ -576,24 +572,23 @@ __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
             if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const f32x4*>(inb + ((int64_t)gy * W + gx) * p.in_cs + c4 * 4);
             *reinterpret_cast<f32x4*>(tile + u * 4) = v;
         }
-        for (int u = tid; u < KS * KS * 16; u += 256) {                      // wl[tap][co][ci] <- wk[tap][c4 * 4 + ci][co]
-            const int tap = u >> 4, co = (u >> 2) & 3, ci = u & 3;
-            wl[u] = wk[((size_t)tap * CinP + c4 * 4 + ci) * 4 + co];
-        }
         __syncthreads();
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(tile + ((ty + ky) * PS + tx + kx) * 4);
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + ((ky * KS + kx) * 4 + (tid & 3)) * 4);
+                const f32x4* wt = wk + (size_t)(ky * KS + kx) * CinP + c4 * 4;      // wave-uniform
 #pragma unroll
-                for (int ci = 0; ci < 4; ++ci) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[ci], xv[ci], acc, 0, 0, 0);
+                for (int ci = 0; ci < 4; ++ci) {
+                    const f32x4 wv = wt[ci];
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(xv[ci], wv[co], acc[co]);
+                }
             }
     }
     const int oy = y0 + ty, ox = x0 + tx;
-    const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, a4);
+    if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, acc);
 }
 
 template <int KS>
