@@ -591,9 +591,71 @@ __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
     if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, acc);
 }
 
+// The same conv with the WHOLE channel depth of the halo tile staged at once (round 4).  The kernel above stages four channels at a time: 16 bytes out of every
+// pixel's 128-byte line per pass, eight passes -- the cache hierarchy moves every line eight times (6.7 GB for SRCNN's 5x5 tail on 4 x 1024 x 1024, which is what
+// its 0.73 ms were; neither packed FMAs nor the matrix core moved it).  Here a pixel's CinP channels are staged once, as whole lines, at a pixel stride of
+// CinP * 4 + 16 bytes (an odd number of 16-byte slots: the 16 lanes of a ds_read_b128 group land on distinct slots), all the layer's weights beside them as
+// [chunk][tap][cout][ci], and the multiply-adds run on v_mfma_f32_4x4x1_16B_f32: sixteen independent 4 x 4 x 1 blocks per instruction = 4 couts x 64 pixels, a lane's
+// four result registers its pixel's couts.  One k step = one (tap, channel) in the order (4-channel chunk, ky, kx, channel) of the kernel above, each a fused
+// multiply-add per output: bit for bit the same sums.
+template <int KS>
+__global__ void __launch_bounds__(256) conv_fewcout_full_kernel(ConvParams p) {
+    constexpr int TS = 16, PS = TS + KS - 1, PADK = (KS - 1) / 2, NTAP = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int CinP = p.nchunks * 4, PSTR = CinP + 4;                        // floats per staged pixel
+    float* tile = reinterpret_cast<float*>(smem);
+    float* wl = tile + PS * PS * PSTR;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int b = blockIdx.z, y0 = blockIdx.y * TS, x0 = blockIdx.x * TS;
+    const int H = p.H, W = p.W;
+    const float* inb = reinterpret_cast<const float*>(p.in) + (int64_t)b * H * W * p.in_cs + p.in_coff;
+    const float* __restrict__ wk = reinterpret_cast<const float*>(p.w);      // [tap][CinP][4]
+    const int nsl = p.nchunks;                                               // 16-byte slices per pixel
+    for (int u = tid; u < PS * PS * nsl; u += 256) {
+        const int pix = u / nsl, sl = u - pix * nsl;
+        const int py = pix / PS, px = pix - py * PS;
+        const int gy = y0 + py - PADK, gx = x0 + px - PADK;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const f32x4*>(inb + ((int64_t)gy * W + gx) * p.in_cs + sl * 4);
+        *reinterpret_cast<f32x4*>(tile + pix * PSTR + sl * 4) = v;
+    }
+    for (int u = tid; u < nsl * NTAP * 16; u += 256) {                        // wl[c4][tap][co][ci] <- wk[tap][c4 * 4 + ci][co]
+        const int ci = u & 3, co = (u >> 2) & 3, tap = (u >> 4) % NTAP, c4 = (u >> 4) / NTAP;
+        wl[u] = wk[((size_t)tap * CinP + c4 * 4 + ci) * 4 + co];
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c4 = 0; c4 < nsl; ++c4) {
+        const float* wc = wl + (c4 * NTAP * 4 + (tid & 3)) * 4;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(tile + ((ty + ky) * PS + tx + kx) * PSTR + c4 * 4);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wc + (ky * KS + kx) * 16);
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[ci], xv[ci], acc, 0, 0, 0);
+            }
+    }
+    const int oy = y0 + ty, ox = x0 + tx;
+    const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, a4);
+}
+
 template <int KS>
 int launch_fewcout(sr_ctx* ctx, const ConvParams& p, hipStream_t st) {
     if (p.B > 65535 || (p.H + 15) / 16 > 65535) return ctx->fail(SR_ERR_INVALID, "conv: too many tiles for one launch");
+    constexpr int PS = 16 + KS - 1;
+    const int CinP = p.nchunks * 4;
+    const int lds = PS * PS * (CinP + 4) * 4 + p.nchunks * KS * KS * 16 * 4;
+    static const bool chunked = getenv("SR355_FEW_CHUNKED") != nullptr;      // A/B switch (diagnostic): round 3's four-channels-at-a-time kernel
+    if (!chunked && lds <= 80 * 1024 && (p.in_cs & 3) == 0 && (p.in_coff & 3) == 0) {      // two workgroups per CU
+        auto kern = conv_fewcout_full_kernel<KS>;
+        if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3((p.W + 15) / 16, (p.H + 15) / 16, p.B), dim3(256), lds, st, p);
+        SR_HIP(ctx, hipGetLastError());
+        return SR_OK;
+    }
     hipLaunchKernelGGL(conv_fewcout_f32_kernel<KS>, dim3((p.W + 15) / 16, (p.H + 15) / 16, p.B), dim3(256), 0, st, p);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
