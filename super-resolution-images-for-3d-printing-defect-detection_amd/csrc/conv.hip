@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(256) conv_fewcout_f32_kernel(ConvParams p) {
 // CinP * 4 + 16 bytes (an odd number of 16-byte slots: the 16 lanes of a ds_read_b128 group land on distinct slots), all the layer's weights beside them as
 // [chunk][tap][cout][ci], and the multiply-adds run on v_mfma_f32_4x4x1_16B_f32: sixteen independent 4 x 4 x 1 blocks per instruction = 4 couts x 64 pixels, a lane's
 // four result registers its pixel's couts.  One k step = one (tap, channel) in the order (4-channel chunk, ky, kx, channel) of the kernel above, each a fused
-// multiply-add per output: bit for bit the same sums.
+// multiply-add per output.
 template <int KS>
 __global__ void __launch_bounds__(256) conv_fewcout_full_kernel(ConvParams p) {
     constexpr int TS = 16, PS = TS + KS - 1, PADK = (KS - 1) / 2, NTAP = KS * KS;
@@ -624,7 +624,11 @@ __global__ void __launch_bounds__(256) conv_fewcout_full_kernel(ConvParams p) {
         wl[u] = wk[((size_t)tap * CinP + c4 * 4 + ci) * 4 + co];
     }
     __syncthreads();
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // four independent chains, one per channel of a slice (a single chain of 800 dependent MFMAs ran at their latency with two waves per SIMD: 0.60 ms for
+    // SRCNN's tail on 4 x 1024 x 1024), added pairwise at the end
+    f32x4 acc[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) acc[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c4 = 0; c4 < nsl; ++c4) {
         const float* wc = wl + (c4 * NTAP * 4 + (tid & 3)) * 4;
 #pragma unroll
@@ -634,11 +638,13 @@ __global__ void __launch_bounds__(256) conv_fewcout_full_kernel(ConvParams p) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(tile + ((ty + ky) * PS + tx + kx) * PSTR + c4 * 4);
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(wc + (ky * KS + kx) * 16);
 #pragma unroll
-                for (int ci = 0; ci < 4; ++ci) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[ci], xv[ci], acc, 0, 0, 0);
+                for (int ci = 0; ci < 4; ++ci) acc[ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[ci], xv[ci], acc[ci], 0, 0, 0);
             }
     }
     const int oy = y0 + ty, ox = x0 + tx;
-    const float a4[4] = {acc[0], acc[1], acc[2], acc[3]};
+    float a4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a4[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
     if (oy < H && ox < W) epilogue4<float>(p, b, oy, ox, 0, a4);
 }
 
