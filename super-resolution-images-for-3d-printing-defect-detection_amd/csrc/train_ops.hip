@@ -266,45 +266,46 @@ __global__ void space_to_depth_kernel(const float* x, int B, int H, int W, int C
     }
 }
 
-// C[b] = alpha * op(A[b]) op(B[b]), fp32 row-major, op = identity or transpose; a plain LDS-tiled SGEMM (64 x 64 tile, 4 x 4 per thread):
-// the materialised attention of the TRAINING patches (N = 576 / 2304 tokens, ESRGAN_model.py:57-65) and its backward products.  Not a
-// hot-path kernel: inference attention is the streaming kernel of attention.hip.
+// C[b] = alpha * op(A[b]) op(B[b]), fp32 row-major, op = identity or transpose: the materialised attention of the TRAINING patches (N = 576 / 2304 tokens,
+// ESRGAN_model.py:57-65) and its backward products.  64 x 64 tile per workgroup, 16 k per stage through LDS; round 4: the products run on v_mfma_f32_32x32x2_f32
+// (a wave owns a 32 x 32 quarter of the tile: 8 MFMAs per stage where 256 lanes x 16 v_fma stood: 270 -> ~70 us for the 2304-token products) and a
+// non-transposed operand is staged with the lanes running along k, its contiguous axis (round 3 read it with a stride of K floats between lanes).
+// Not a hot-path kernel: inference attention is the streaming kernel of attention.hip.
 __global__ void __launch_bounds__(256) sgemm_kernel(const float* A, const float* Bm, float* C, int M, int N, int K, int tA, int tB, float alpha,
                                                     int64_t sA, int64_t sB, int64_t sC) {
     __shared__ float As[16][64 + 1], Bs[16][64 + 1];
     const float* a = A + (int64_t)blockIdx.z * sA;
     const float* b = Bm + (int64_t)blockIdx.z * sB;
     float* c = C + (int64_t)blockIdx.z * sC;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float acc[4][4] = {};
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int k0 = 0; k0 < K; k0 += 16) {
         for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-            const int kk = e / 64, mm = e - kk * 64;
-            const int gm = m0 + mm, gk = k0 + kk;
-            As[kk][mm] = (gm < M && gk < K) ? (tA ? a[(int64_t)gk * M + gm] : a[(int64_t)gm * K + gk]) : 0.f;
-            const int gn = n0 + mm;
-            Bs[kk][mm] = (gn < N && gk < K) ? (tB ? b[(int64_t)gn * K + gk] : b[(int64_t)gk * N + gn]) : 0.f;
+            {   // A tile: As[kk][mm] = op(A)[m0 + mm][k0 + kk]
+                const int kk = tA ? e >> 6 : e & 15, mm = tA ? e & 63 : e >> 4;
+                const int gm = m0 + mm, gk = k0 + kk;
+                As[kk][mm] = (gm < M && gk < K) ? (tA ? a[(int64_t)gk * M + gm] : a[(int64_t)gm * K + gk]) : 0.f;
+            }
+            {   // B tile: Bs[kk][nn] = op(B)[k0 + kk][n0 + nn]
+                const int kk = tB ? e & 15 : e >> 6, nn = tB ? e >> 4 : e & 63;
+                const int gn = n0 + nn, gk = k0 + kk;
+                Bs[kk][nn] = (gn < N && gk < K) ? (tB ? b[(int64_t)gn * K + gk] : b[(int64_t)gk * N + gn]) : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-        }
+        for (int kk = 0; kk < 16; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + k][wm + i], Bs[kk + k][wn + i], acc, 0, 0, 0);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
-            if (gm < M && gn < N) c[(int64_t)gm * N + gn] = alpha * acc[i][j];
-        }
+    for (int e = 0; e < 16; ++e) {
+        const int gm = m0 + wm + (e & 3) + 8 * (e >> 2) + 4 * k, gn = n0 + wn + i;      // C/D layout of the 32x32 MFMA: column = lane & 31, row from the register index
+        if (gm < M && gn < N) c[(int64_t)gm * N + gn] = alpha * acc[e];
+    }
 }
 
 // row softmax (in place) and its backward ds = p * (dp - sum_j dp_j p_j): one workgroup per row
