@@ -506,3 +506,19 @@ def test_vgg16_fit_frozen_base(ctx, tmp_path):
     assert hb.history["loss"] == hist.history["loss"] and hb.history["val_accuracy"] == hist.history["val_accuracy"]
     assert all(np.array_equal(b.weights[n][0], w0[n][0]) for n in w0 if n.startswith("block"))
     assert all(np.array_equal(b.weights[n][0], m.weights[n][0]) for n in ("dense", "predictions"))
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16), (3, 70, 45, 8), (1, 129, 33, 37), (2, 576, 32, 576)])        # (batch, M, N, K): tile-exact, ragged, K not a multiple of 16, the trunk attention's beta h
+def test_matmul_all_transposes(ctx, shape, ta, tb):
+    """sr_matmul (the training attention's products: s = g f^T, o = beta h and their four backward products) on the fp32 matrix core, against fp64 NumPy."""
+    B, M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((B, K, M) if ta else (B, M, K)).astype(np.float32)
+    b = rng.standard_normal((B, N, K) if tb else (B, K, N)).astype(np.float32)
+    got = ctx.matmul(ctx.to_device(a), ctx.to_device(b), trans_a=ta, trans_b=tb, alpha=0.5).cpu().numpy()
+    A = a.transpose(0, 2, 1) if ta else a
+    Bm = b.transpose(0, 2, 1) if tb else b
+    ref = 0.5 * np.matmul(A.astype(np.float64), Bm.astype(np.float64))
+    assert got.shape == ref.shape == (B, M, N)
+    assert np.abs(got - ref).max() <= 2e-6 * np.sqrt(K) * max(1.0, np.abs(ref).max())
