@@ -1109,6 +1109,7 @@ int sr_conv2d_dev(sr_ctx* ctx, const void* x, int B, int H, int W, int Cin, cons
     }
     ConvEpilogue ep;
     ep.act = act; ep.alpha = alpha; ep.clip01 = clip01; ep.d2s_r = d2s_r < 1 ? 1 : d2s_r;
+    ep.allow_splitk = 1;
     if (skip1) { ep.skip1 = {skip1, Cout, 0}; ep.beta1 = beta1; }
     if (skip2) { ep.skip2 = {skip2, Cout, 0}; ep.beta2 = beta2; }
     const int r = ep.d2s_r;
@@ -1134,6 +1135,7 @@ int sr_conv2d_dev_views(sr_ctx* ctx, const sr_view* x, int B, int H, int W, int 
     if (cw.thin || cw.CinP != Cin) return ctx->fail(SR_ERR_INVALID, "conv views: the input channel count must be a whole number of the kernel's channel chunks (16 fp32 channels)");
     ConvEpilogue ep;
     ep.act = act; ep.alpha = alpha;
+    ep.allow_splitk = 1;
     if (skip1 && skip1->p) { ep.skip1 = {skip1->p, skip1->cs, skip1->coff}; ep.beta1 = beta1; }
     return conv_launch(ctx, cw, TensorView{x->p, x->cs, x->coff}, B, H, W, TensorView{y->p, y->cs, y->coff}, ep, st);
 }

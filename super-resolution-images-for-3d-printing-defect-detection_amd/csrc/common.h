@@ -164,6 +164,8 @@ struct ConvEpilogue {
     int clip01 = 0;
     int d2s_r = 1;            // depth_to_space block (1 = none)
     int out_f32 = 0;          // write fp32 even when computing in bf16
+    int allow_splitk = 0;     // fp32 3x3: small problems may split K across the waves of a workgroup (conv_wide_sk_kernel) -- another summation order than the tile kernel's,
+                              // so only the training entry points set it: a model's forward must give the same bits whatever the batch it is called with (Keras predict's chunking)
 };
 
 // host: pack HWIO fp32 weights (+bias) for the device.  Returns SR_OK or error (ctx->err set).

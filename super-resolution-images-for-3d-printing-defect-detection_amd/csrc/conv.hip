@@ -460,7 +460,7 @@ int launch_wide(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
             // still fewer than one 8 x 16 tile per CU: split K inside the workgroup (conv_wide_sk_kernel) -- 4 x the workgroups, a quarter of the chain each
             static const bool no_sk = getenv("SR355_NO_SPLITK") != nullptr;      // A/B switch (diagnostic)
             const int64_t wgs1 = (int64_t)((p0.W + 15) / 16) * ((p0.H + 7) / 8) * p0.B * nct;
-            if (!no_sk && wgs1 < ctx->cu_count()) return launch_wide_sk<KS, KGPT, NT>(ctx, p0, nct, st);
+            if (!no_sk && p0.splitk_ok && wgs1 < ctx->cu_count()) return launch_wide_sk<KS, KGPT, NT>(ctx, p0, nct, st);
         }
         if (wgs3 < 2 * ctx->cu_count()) return launch_wide_mt<T, KS, KGPT, NT, 1>(ctx, p0, nct, st);
     }
@@ -903,6 +903,7 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
     p.f2w = nullptr; p.f2part = nullptr; p.f2c = 0;
     p.pjw = nullptr; p.pjbias = nullptr; p.pjout = nullptr; p.pj_cs = 0; p.pj_coff = 0; p.pj_rs = 0; p.pj_nblk = 0;
     p.cell_h = ep.cell_h; p.cell_w = ep.cell_w;
+    p.splitk_ok = ep.allow_splitk;
     p.pw2w = nullptr; p.pw2bias = nullptr; p.pw2_cout = 0; p.pw2_act = 0;
     p.plout = nullptr; p.pl_cs = 0; p.pl_coff = 0; p.pl_gx = p.pl_ch = p.pl_cw = p.pl_Wv = 0;
     const int osz = p.out_f32 ? 4 : esz;

@@ -35,6 +35,7 @@ struct ConvParams {
     char* pjout; int64_t pj_cs; int pj_coff; int pj_rs; int pj_nblk;
     // fp32 thin kernel, fused 1x1 (conv.hip): the conv's activation feeds a 1x1 conv to <= 32 channels from the accumulators; only that is stored
     const float* pw2w; const float* pw2bias; int pw2_cout, pw2_act;
+    int splitk_ok;      // fp32 3x3 wide kernel: the split-K variant may be chosen (training entry points only)
     int cell_h, cell_w; // conv_rows fast epilogue: separator rows / columns of a CellGrid layout are not stored (0 = none)
     // conv_rows, fused 2x2 max-pool (conv_rows.hip, rows_pool2): the conv's output is not stored; its VALID 2x2 / stride-2 maximum goes to plout
     // ([B][H/2][W/2] NHWC pixels of pl_cs channels, or packed in a CellGrid: pl_gx images per row of cells of pl_ch x pl_cw pixels, pl_Wv pixels per row)
