@@ -1074,6 +1074,7 @@ int sr_conv2d(sr_ctx* ctx, const void* x, int dtype, int B, int H, int W, int Ci
     if (!rc) {
         ConvEpilogue ep;
         ep.act = act; ep.alpha = alpha; ep.clip01 = clip01; ep.d2s_r = d2s_r < 1 ? 1 : d2s_r;
+        ep.allow_splitk = 1;                                      // a single op, like sr_conv2d_dev (same kernel choice: the two agree bit for bit); model forwards do not set it
         if (skip1) { ep.skip1 = {skip1, Cout, 0}; ep.beta1 = beta1; }
         if (skip2) { ep.skip2 = {skip2, Cout, 0}; ep.beta2 = beta2; }
         const int r = ep.d2s_r;
