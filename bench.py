@@ -100,20 +100,22 @@ def cpu_baseline(weights, lr_tile, budget_s=20.0, keep=None):
                       f"on a {n_cpu}-CPU host), {dt:.1f} s, extrapolated to a 441-patch tile"}
 
 
-def parity_object(ctx, model, weights, lr_tile, hr_tile, fp32_ref, io="bf16"):
+def parity_object(ctx, model, weights, lr_tile, hr_tile, fp32_ref, io="bf16", like_for_like=None):
     """GPU (the bench's bf16 generator) vs the oracle on the PARITY_IDX LR patches of tile 0, outside the timed region.
     Like-for-like = the oracle in its bf16-storage mode (rounds to bf16 where the device stores bf16); the plain fp32 reference
     graph is reported beside it.  abs_psnr_delta_vs_hr_db is the north star's figure |PSNR(gpu, HR) - PSNR(oracle, HR)| (<= 0.01 dB),
     per patch, worst case, against the fp32 reference graph (and against the bf16-storage oracle beside it).
     io: dtype of the caller's tensors -- "f32" is what super_resolve_image hands the generator (fp32 patches in, fp32 image out: the
     product path of the timed step), "bf16" a caller that keeps its tensors in bf16 (the generator's output is then rounded once more).
-    fp32_ref: the fp32 reference graph's outputs for these patches if already computed (cpu_baseline), else None = computed here."""
+    fp32_ref: the fp32 reference graph's outputs for these patches if already computed (cpu_baseline), else None = computed here.
+    like_for_like: how many of the patches the bf16-storage oracle is run on (None = all; it is the second CPU forward per patch)."""
     from oracle import models as OM
     from oracle import ops as OO
     from sr355.weights import round_to_bf16
     x = round_to_bf16(tile_patches(lr_tile)[PARITY_IDX].astype(np.float32))
     got = model.generator.forward(ctx.to_device(x, torch.bfloat16 if io == "bf16" else torch.float32)).float().cpu().numpy()
-    ref = np.concatenate([OM.esrgan_g_forward(x[i:i + 2], weights, SCALE, NB, bf16_storage=True, bf16_output=io == "bf16") for i in range(0, len(x), 2)])
+    nl = len(x) if like_for_like is None else max(2, min(len(x), int(like_for_like)))
+    ref = np.concatenate([OM.esrgan_g_forward(x[i:i + 2], weights, SCALE, NB, bf16_storage=True, bf16_output=io == "bf16") for i in range(0, nl, 2)])
     if fp32_ref is None:
         fp32_ref = np.concatenate([OM.esrgan_g_forward(x[i:i + 2], weights, SCALE, NB) for i in range(0, len(x), 2)])
     hr = hr_patches(hr_tile, PARITY_IDX).astype(np.float64)
@@ -121,10 +123,10 @@ def parity_object(ctx, model, weights, lr_tile, hr_tile, fp32_ref, io="bf16"):
     p01 = lambda a, b: OO.psnr(to01(a), to01(b), dtype=np.float64)
     vs_hr = lambda a: OO.psnr(hr, to01(a), dtype=np.float64)
     f32r = fp32_ref[:len(x)]
-    return {"psnr_gpu_vs_oracle_db": float(p01(got, ref).min()), "max_abs": float(np.abs(got - ref).max()),
-            "rel_l2": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "n_patches": int(len(x)), "caller_tensors": io,
+    return {"psnr_gpu_vs_oracle_db": float(p01(got[:nl], ref).min()), "max_abs": float(np.abs(got[:nl] - ref).max()),
+            "rel_l2": float(np.linalg.norm(got[:nl] - ref) / np.linalg.norm(ref)), "n_patches": int(len(x)), "n_patches_bf16_storage_oracle": int(nl), "caller_tensors": io,
             "patches": "4 x 4 grid over tile 0's 21 x 21 patch positions (rows/cols 0, 6, 13, 19)",
-            "abs_psnr_delta_vs_hr_db_bf16_storage_oracle": float(np.abs(vs_hr(got) - vs_hr(ref)).max()),
+            "abs_psnr_delta_vs_hr_db_bf16_storage_oracle": float(np.abs(vs_hr(got)[:nl] - OO.psnr(hr[:nl], to01(ref), dtype=np.float64)).max()),
             "oracle": "CPU restatement, fp32 arithmetic, bf16 storage where the device stores bf16 (oracle.models bf16_storage=True)",
             "psnr_gpu_vs_fp32_reference_graph_db": float(p01(got, f32r).min()),
             "psnr_fp32_reference_graph_vs_hr_db": [float(vs_hr(f32r).min()), float(vs_hr(f32r).max())],
@@ -167,7 +169,7 @@ def trained_like_parity(ctx, model_bf16, lr4, hr4, levels=TRAINED_LIKE_LEVELS, l
         model_bf16.set_weights(w)
         m32.set_weights(w)
         f32r = np.concatenate([OM.esrgan_g_forward(x[i:i + 2], w, SCALE, NB) for i in range(0, len(x), 2)])
-        o = parity_object(ctx, model_bf16, w, lr4[0], hr4[0], f32r, io="f32")
+        o = parity_object(ctx, model_bf16, w, lr4[0], hr4[0], f32r, io="f32", like_for_like=4)
         g32 = m32.generator.forward(ctx.to_device(x, torch.float32)).cpu().numpy()
         o["psnr_gpu_f32_vs_fp32_reference_graph_db"] = float(OO.psnr(to01(g32), to01(f32r), dtype=np.float64).min())
         tiles = []
