@@ -186,10 +186,10 @@ __global__ void __launch_bounds__(256) conv_wide_kernel(ConvParams p) {
 // at the end the four partial accumulators meet in LDS and wave w adds them -- always in the order 0, 1, 2, 3: deterministic, no atomics -- for the
 // four-cout groups q = w, then runs the usual epilogue.  Four times the workgroups, a quarter of the serial MFMA chain each; the weights of a chunk
 // are staged per 32 pixels instead of per 128 (L2 -> LDS at 59 B/clk per CU: ~3.5 us for conv5's 432 KiB, under the 13 us of MFMAs).
+// (Round 4 also measured the chunk's weights by LDS-DMA into two buffers, a chunk ahead, instead of through registers: 55.8 ms per cfg3 step against 54.5-56.7 --
+//  the weight stage is not what a chunk waits for; removed.)
 // ------------------------------------------------------------------------------------------------
-// DMA: the chunk's weights (already in LDS order in memory) go global -> LDS by LDS-DMA into one of two buffers, a chunk ahead, instead of through registers and
-// ds_write_b128 (36 KiB per chunk at NT = 2: the register path's stores took about as long as the chunk's MFMAs).
-template <int KS, int KGPT, int NT, bool DMA>
+template <int KS, int KGPT, int NT>
 __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
     typedef f32x4 frag;
     constexpr int E = 4;
@@ -207,8 +207,7 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
     char* lin = smem;
     char* lw = smem + LIN_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     int t = blockIdx.x;
     const int tx = t % p.tilesX; t /= p.tilesX;
     const int ty = t % p.tilesY;
@@ -231,8 +230,7 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
     }
     // both the next chunk's pixels and its weights fly under the current chunk's MFMAs: with a quarter of the chain per wave the weight stage's
     // round trip (36 KiB per chunk at NT = 2) would otherwise be as long as the chunk's arithmetic
-    constexpr int NWT = DMA ? 1 : (WUNITS + 255) / 256;
-    constexpr int NPIECE = WUNITS / 64;                             // 1 KiB pieces of a chunk's weights
+    constexpr int NWT = (WUNITS + 255) / 256;
     frag pre[NINT], wpre[NWT];
     auto issue = [&](int chunk) {
 #pragma unroll
@@ -243,17 +241,10 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
             pre[i] = so >= 0 ? v : z;
         }
         const char* wsrc = p.w + ((int64_t)ct * p.nchunks + chunk) * (int64_t)(WUNITS * 16);
-        if constexpr (DMA) {
-            char* wdst = lw + (chunk & 1) * (WUNITS * 16);
-            for (int q = wave; q < NPIECE; q += 4)                 // wave-uniform piece index: a 1 KiB piece per wave instruction
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + q * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(wdst + q * 1024), 16, 0, 0);
-        } else {
 #pragma unroll
-            for (int i = 0; i < NWT; ++i) {
-                const int u = tid + 256 * i;
-                wpre[i] = *reinterpret_cast<const f32x4*>(wsrc + (u < WUNITS ? u : 0) * 16);
-            }
+        for (int i = 0; i < NWT; ++i) {
+            const int u = tid + 256 * i;
+            wpre[i] = *reinterpret_cast<const f32x4*>(wsrc + (u < WUNITS ? u : 0) * 16);
         }
     };
     const int abase = ((r >> 4) * PW + (r & 15)) * CS + h * 16;
@@ -269,17 +260,13 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < NINT; ++i)
             if (doff[i] >= 0) *reinterpret_cast<frag*>(lin + doff[i]) = pre[i];
-        if constexpr (DMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of chunk `chunk` (and the pixels just written from `pre`) have landed; the barrier publishes everybody's
-        } else {
 #pragma unroll
-            for (int i = 0; i < NWT; ++i) {
-                const int u = tid + 256 * i;
-                if (u < WUNITS) *reinterpret_cast<f32x4*>(lw + u * 16) = wpre[i];
-            }
+        for (int i = 0; i < NWT; ++i) {
+            const int u = tid + 256 * i;
+            if (u < WUNITS) *reinterpret_cast<f32x4*>(lw + u * 16) = wpre[i];
         }
         __syncthreads();
-        if (chunk + 1 < p.nchunks) issue(chunk + 1);               // DMA: into the other buffer, whose last readers passed the barrier above
+        if (chunk + 1 < p.nchunks) issue(chunk + 1);
 #pragma unroll
         for (int g0 = 0; g0 < NKG; g0 += 4) {
             const int g = g0 + wave;                               // wave-uniform
@@ -289,7 +276,7 @@ __global__ void __launch_bounds__(256) conv_wide_sk_kernel(ConvParams p) {
                 const frag xf = *reinterpret_cast<const frag*>(lin + abase + toff + kg * 32);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const frag wf = *reinterpret_cast<const frag*>(lw + (DMA ? (chunk & 1) * (WUNITS * 16) : 0) + (g * NT + n) * 1024 + lane * 16);
+                    const frag wf = *reinterpret_cast<const frag*>(lw + (g * NT + n) * 1024 + lane * 16);
                     acc[n] = mma(wf, xf, acc[n]);
                 }
             }
@@ -324,13 +311,11 @@ template <int KS, int KGPT, int NT>
 int launch_wide_sk(sr_ctx* ctx, const ConvParams& p0, int nct, hipStream_t st) {
     constexpr int PH = 2 + KS - 1, PW = 16 + KS - 1;
     constexpr int CS = KGPT * 32 + 16;
-    constexpr int WBYTES = KS * KS * KGPT * NT * 1024;
-    constexpr bool DMA = 2 * WBYTES <= 76 * 1024;                   // two weight buffers and still two workgroups per CU
-    constexpr int lds = ((PH * PW * CS + 15) & ~15) + (DMA ? 2 : 1) * WBYTES;
+    constexpr int lds = ((PH * PW * CS + 15) & ~15) + KS * KS * KGPT * NT * 1024;
     ConvParams p = p0;
     p.tilesX = (p.W + 15) / 16;
     p.tilesY = (p.H + 1) / 2;
-    auto kern = conv_wide_sk_kernel<KS, KGPT, NT, DMA>;
+    auto kern = conv_wide_sk_kernel<KS, KGPT, NT>;
     if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     dim3 grid((unsigned)((int64_t)p.tilesX * p.tilesY * p.B), (unsigned)nct);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
