@@ -283,20 +283,35 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const float* A, const float*
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+    // a thread stages elements e = tid + 256 j (j < 4) of either tile; the next stage's values are requested before this stage's MFMAs (the kernel
+    // ran at one global round trip per 16 k: 240 us for the 2304-token products)
+    float pa[4], pb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = threadIdx.x + 256 * j;
             {   // A tile: As[kk][mm] = op(A)[m0 + mm][k0 + kk]
                 const int kk = tA ? e >> 6 : e & 15, mm = tA ? e & 63 : e >> 4;
                 const int gm = m0 + mm, gk = k0 + kk;
-                As[kk][mm] = (gm < M && gk < K) ? (tA ? a[(int64_t)gk * M + gm] : a[(int64_t)gm * K + gk]) : 0.f;
+                pa[j] = (gm < M && gk < K) ? (tA ? a[(int64_t)gk * M + gm] : a[(int64_t)gm * K + gk]) : 0.f;
             }
             {   // B tile: Bs[kk][nn] = op(B)[k0 + kk][n0 + nn]
                 const int kk = tB ? e & 15 : e >> 6, nn = tB ? e >> 4 : e & 63;
                 const int gn = n0 + nn, gk = k0 + kk;
-                Bs[kk][nn] = (gn < N && gk < K) ? (tB ? b[(int64_t)gn * K + gk] : b[(int64_t)gk * N + gn]) : 0.f;
+                pb[j] = (gn < N && gk < K) ? (tB ? b[(int64_t)gn * K + gk] : b[(int64_t)gk * N + gn]) : 0.f;
             }
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            As[tA ? e >> 6 : e & 15][tA ? e & 63 : e >> 4] = pa[j];
+            Bs[tB ? e & 15 : e >> 6][tB ? e >> 4 : e & 63] = pb[j];
+        }
         __syncthreads();
+        if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + k][wm + i], Bs[kk + k][wn + i], acc, 0, 0, 0);
         __syncthreads();
