@@ -7,8 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SR355_LIB_PATH: a builder's A/B switch (another build of the same library, e.g. an experiment variant of one kernel); never a fallback
-LIB_PATH = os.environ.get("SR355_LIB_PATH") or os.path.join(_HERE, "libsr355.so")
+LIB_PATH = os.path.join(_HERE, "libsr355.so")
 
 SR_OK = 0
 SR_ERR_INVALID, SR_ERR_HIP, SR_ERR_OOM, SR_ERR_STATE, SR_ERR_NAME, SR_ERR_CAPACITY = -1, -2, -3, -4, -5, -6
