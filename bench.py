@@ -432,6 +432,23 @@ def main():
         fence()
         elapsed_prof = time.perf_counter() - t1
         prof = ctx.profile_end()
+    # DVFS diagnostic inside the run (MI355X_MICROARCH.md "DVFS give-back" item 1; N = 1 only, outside the timed region): the same launches once more on
+    # all-zero weights and tiles -- what the dominant kernel's instruction stream sustains when no operand bit toggles and the chip keeps its clock
+    zero_prof = None
+    if not args.no_profile and world == 1 and not args.zero_data and n_mine:
+        zw = {n: (np.zeros_like(k), np.zeros_like(b)) for n, (k, b) in weights.items()}
+        lr_keep = lr
+        for m_ in models:
+            m_.set_weights(zw)
+        lr = torch.full_like(lr_keep, 0.5)
+        step()
+        ctx.profile_begin()
+        step()
+        fence()
+        zero_prof = ctx.profile_end()
+        lr = lr_keep
+        for m_ in models:
+            m_.set_weights(weights)
     et = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
     D.allreduce_max(et)
     elapsed = float(et.item())
@@ -447,6 +464,15 @@ def main():
             traffic, traffic_note = pmc_traffic(dom["kernel"])
             roof = roofline_object(dom, traffic, elapsed_prof / args.steps * 1e3, clock_mhz)
             roof["traffic_source"] = traffic_note
+            if zero_prof:
+                z = next((r for r in zero_prof if r["kernel"] == dom["kernel"]), None)
+                if z:
+                    zt = z["flops"] / (z["total_ms"] * 1e-3) / 1e12
+                    roof["same_kernel_on_all_zero_operands"] = {
+                        "tflops": zt, "frac": zt / PEAK_BF16_TFLOPS, "avg_launch_ms": z["total_ms"] / z["launches"], "ratio_to_real_data": zt / roof["achieved"],
+                        "step_ms": sum(r["total_ms"] for r in zero_prof),
+                        "note": "one extra step on zero weights and tiles, same launches: the instruction stream's rate at the clock the chip holds when no operand bit toggles; "
+                                "the difference to `achieved` is clock the chip gives back under data-dependent power, not issue slots (DESIGN.md 3.8)"}
         line = {
             "metric": "4x-SR MPix/s on 512x512 LR batch", "value": mpix * args.steps / elapsed, "unit": "MPix/s",
             "n_gpus": group_world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
