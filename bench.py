@@ -435,6 +435,7 @@ def main():
     # DVFS diagnostic inside the run (MI355X_MICROARCH.md "DVFS give-back" item 1; N = 1 only, outside the timed region): the same launches once more on
     # all-zero weights and tiles -- what the dominant kernel's instruction stream sustains when no operand bit toggles and the chip keeps its clock
     zero_prof = None
+    res = out.cpu().numpy()                      # the metric sums of the measured steps (the diagnostic below overwrites the device tensor)
     if not args.no_profile and world == 1 and not args.zero_data and n_mine:
         zw = {n: (np.zeros_like(k), np.zeros_like(b)) for n, (k, b) in weights.items()}
         lr_keep = lr
@@ -452,7 +453,6 @@ def main():
     et = torch.tensor([elapsed], dtype=torch.float64, device=ctx.torch_device)
     D.allreduce_max(et)
     elapsed = float(et.item())
-    res = out.cpu().numpy()
 
     if rank == 0:
         mpix = global_tiles * (LR * SCALE) ** 2 / 1e6
