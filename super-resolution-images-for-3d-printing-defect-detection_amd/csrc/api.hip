@@ -119,6 +119,7 @@ struct Op {
     int dw = -1, db = -1, In = 0, Out = 0;          // dense: param indices
     int chain = -1, chain_pos = 0;                  // conv: member (first / second) of m->chains[chain]
     int rgbtail = -1;                               // conv: first op of m->rgbtails[rgbtail] (the next op is the conv folded into this one's epilogue)
+    int pack_alt = -1;                              // conv (ESRGAN trunk_conv): a free row-blocked buffer the two-up packed trunk output is unpacked into (sr_forward, 24-pixel-wide patches)
     int pw2 = -1;                                   // conv: the next op is the 1x1 conv m->pw2s[pw2], which this fp32 thin conv's epilogue can compute from its accumulators
     int proj = -1;                                  // conv: the next op is the 1x1 projection m->projs[proj], which this conv's epilogue can compute
 };
@@ -324,7 +325,7 @@ int build_esrgan(sr_model* m) {
         const int nX = Y, nY = Z, nZ = X; X = nX; Y = nY; Z = nZ;
     }
     const int t2 = b.buf(64);
-    { Op& o = b.conv("trunk_conv", 3, 64, 64, {cat[X], 0}, {t2, 0}); o.skip1 = {trunk, 0}; o.beta1 = 1.f; }
+    { Op& o = b.conv("trunk_conv", 3, 64, 64, {cat[X], 0}, {t2, 0}); o.skip1 = {trunk, 0}; o.beta1 = 1.f; o.pack_alt = cat[Y]; }
     int cur = t2;
     if (c.use_attention) {
         const int qkv = b.buf(64), ao = b.buf(32), t3 = b.buf(64);
@@ -881,7 +882,11 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
     if (m->kind == SR_MODEL_VGG16 && (H < 32 || W < 32)) return ctx->fail(SR_ERR_INVALID, "VGG16 needs H,W >= 32");
     if (m->kind == SR_MODEL_VGG19_FEATURES && (H < 16 || W < 16)) return ctx->fail(SR_ERR_INVALID, "VGG19 features need H,W >= 16");
     const bool use_cells = m->taps.empty() && (ctx->chain_mask & 16) != 0;
-    int rc = ensure_workspace(m, B, H, W, st, use_cells);
+    // 24-pixel-wide patches (patch_size_lr = 24: the reference's own training patch, ESRGAN_model.py:858 / constants.py:8) through the fused dense-block kernels, which are
+    // built for 48-pixel rows: two images side by side per row, [ceil(B / 2)][H][C / 32][48][32], from the trunk's first concat buffer to trunk_conv's input; the kernels
+    // treat columns 23 | 24 as an image border (dense_fused.hip SEAM).  Needs all three fused dense-block kernels (mask bits 0, 1, 5) and no taps.
+    const bool pack2 = m->kind == SR_MODEL_ESRGAN_G && m->T == SR_DTYPE_BF16 && W == 24 && m->taps.empty() && (ctx->chain_mask & 35) == 35 && !m->chains.empty() && B >= 2;
+    int rc = ensure_workspace(m, pack2 ? (B + 1) & ~1 : B, H, W, st, use_cells);
     if (rc) return rc;
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     const int T = m->T;
@@ -905,7 +910,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                     // ring, so such a pair runs layer by layer (the tap used to return stale workspace bytes without an error)
                     const size_t first = op.chain_pos == 0 ? oi : oi - 1;
                     const bool tapped_inner = ch.tail && !m->taps.empty() && m->taps.count((int)first) != 0;
-                    if (!tapped_inner && (ctx->chain_mask & (ch.tail ? 1 : 2)) && chain_supported(ch.w, xin, w)) {
+                    if (!tapped_inner && (ctx->chain_mask & (ch.tail ? 1 : 2)) && chain_supported(ch.w, xin, pack2 ? 48 : w)) {
                         if (op.chain_pos == 0) {                  // the pair runs as one kernel, launched at its first op
                             const Op& ob = m->ops[oi + 1];
                             auto view = [&](const Ref& r) { return r.buf >= 0 ? TensorView{m->bufp[r.buf], m->bufs[r.buf].Cbuf, r.coff, m->bufs[r.buf].blk} : TensorView{}; };
@@ -920,15 +925,25 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                                     if (r.buf == op.in.buf && r.coff == 0) bx = be; else { so = view(r); bo = be; }
                                 }
                             }
-                            rc = chain_launch(ctx, ch.w, xin, B, h, w, outv, so, ob.alpha, bx, bo, st);
+                            rc = pack2 ? chain_launch(ctx, ch.w, xin, (B + 1) / 2, h, 48, outv, so, ob.alpha, bx, bo, st, true)
+                                       : chain_launch(ctx, ch.w, xin, B, h, w, outv, so, ob.alpha, bx, bo, st);
                         }
                         break;
                     }
                 }
                 if ((ctx->chain_mask & 32) && op.chain < 0 && op.act == SR_ACT_RELU && op.alpha == 1.f && op.skip1.buf < 0 && op.skip2.buf < 0 && op.d2s == 1 && !op.clip &&
-                    op.out.buf == op.in.buf && op.in.coff == 0 && op.out.coff == 64 && conv1_stream_supported(cs.w, xin, w)) {
-                    rc = conv1_stream_launch(ctx, cs.w, xin, B, h, w, st);           // conv1 of a dense block: the streaming kernel
+                    op.out.buf == op.in.buf && op.in.coff == 0 && op.out.coff == 64 && conv1_stream_supported(cs.w, xin, pack2 ? 48 : w)) {
+                    rc = pack2 ? conv1_stream_launch(ctx, cs.w, xin, (B + 1) / 2, h, 48, st, true)
+                               : conv1_stream_launch(ctx, cs.w, xin, B, h, w, st);   // conv1 of a dense block: the streaming kernel
                     break;
+                }
+                if (pack2 && op.pack_alt >= 0) {
+                    // trunk_conv: its input, channels [0, 64) of the last dense block's buffer, is two-up packed -- unpacked into a free concat buffer first
+                    rc = unpack_pairs_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.pack_alt], m->bufs[op.pack_alt].Cbuf, 0, st);
+                    if (rc) return rc;
+                    xin = TensorView{m->bufp[op.pack_alt], m->bufs[op.pack_alt].Cbuf, 0, m->bufs[op.pack_alt].blk};
+                } else if (pack2 && m->bufs[op.in.buf].blk) {
+                    return ctx->fail(SR_ERR_STATE, "two-up packed dense blocks: a conv outside the fused kernels would read a packed buffer");
                 }
                 if (op.rgbtail >= 0 && (ctx->chain_mask & 4) && m->taps.count((int)oi) == 0 && cs.w.rows && cs.w.NT == 4 && cs.w.Cout == 64 &&
                     op.skip1.buf < 0 && op.skip2.buf < 0 && op.d2s == 1 && !op.clip && op.act != SR_ACT_TANH && op.out.buf >= 0 &&
@@ -1008,6 +1023,10 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 rc = vgg_preproc_launch(ctx, x, io_dtype, (int64_t)B * H * W, m->bufp[op.out.buf], T, m->bufs[op.out.buf].Cbuf, st);
                 break;
             case OP_TOBLK:
+                if (pack2) {
+                    rc = pack_pairs_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, st);
+                    break;
+                }
                 rc = nhwc_to_blocked_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.out.buf],
                                             m->bufs[op.out.buf].Cbuf, op.out.coff, st);
                 break;

@@ -209,9 +209,11 @@ void chain_free_weights(sr_ctx* ctx, ChainWeights* w);
 bool chain_supported(const ChainWeights& w, const TensorView& in, int W);
 // conv1 of a dense block (64 -> 32, writes chunk 2 of the row-blocked buffer it reads) as a streaming line-buffer kernel (dense_fused.hip)
 bool conv1_stream_supported(const ConvWeights& w, const TensorView& in, int W);
-int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st);
+int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st, bool seam = false);
+int pack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, hipStream_t st);
+int unpack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_C, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, hipStream_t st);
 int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H, int W, TensorView out, TensorView skip_o, float alpha, float beta_x,
-                 float beta_o, hipStream_t st);
+                 float beta_o, hipStream_t st, bool seam = false);
 
 // ---------------------------------------------------------------------------------------------
 // attention core: o = softmax(q k^T) v per image, tokens N=H*W.

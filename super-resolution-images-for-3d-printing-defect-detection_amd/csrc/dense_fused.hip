@@ -136,7 +136,10 @@ constexpr int NCOMP = 8, NLOAD = 4;    // compute waves (one stream row each) + 
 // compute waves issuing the weight pieces themselves (-10 %).  The loaders also keep part (growth pairs: all) of the weights in their spare
 // registers and write them into the slots with ds_write_b128: fewer L2 reads, and whole-line output stores through an LDS transposition
 // (DESIGN.md 3.3 items 2 and 4 stand).
-template <int EXT, int NB0, int NB1, int MODE, bool HAS_O, bool STAMP>
+// SEAM (round 4): the 48-pixel rows hold TWO 24-pixel-wide images side by side (columns 0-23 | 24-47: patch_size_lr = 24, the reference's own training patch,
+// ESRGAN_model.py:858 / constants.py:8, packed by api.hip) -- the only thing the kernel must know is that columns 23 and 24 are not neighbours: the kx = 0 fragment
+// of column 24 and the kx = 2 fragment of column 23 are zero padding (lanes px = 8 resp. 7 of column group 1), exactly as columns -1 and 48 already are.
+template <int EXT, int NB0, int NB1, int MODE, bool HAS_O, bool STAMP, bool SEAM = false>
 __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4) chain2_kernel(ChainParams p) {
     using L = ChainLds<NB0, NB1, MODE>;
     constexpr int NBT = NB0 + NB1, WSLOT = L::WSLOT;
@@ -359,6 +362,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
     const bool edge_l = px == 0, edge_r = px == 15;    // column -1 (kx 0, cg 0) and column 48 (kx 2, cg 2) are padding: fragment forced to zero
     const int off_l = edge_l ? offk[1] : offk[0];      // ... and read from a valid address
     const int off_r = edge_r ? offk[1] : offk[2];
+    const bool seam_l = SEAM && px == 8, seam_r = SEAM && px == 7;      // column group 1: column 24's left neighbour / column 23's right neighbour belong to the other image
 
     f32x4 a0[NB0][3], a1[NB1][3];
 
@@ -431,6 +435,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 const int off = (KX == 0 && cg == 0) ? off_l : (KX == 2 && cg == 2) ? off_r : offk[KX];
                 x[cg] = *reinterpret_cast<const bf16x8*>(rb + d * ROWB + cg * 1024 + off);
                 if ((KX == 0 && cg == 0 && edge_l) || (KX == 2 && cg == 2 && edge_r)) x[cg] = bf16x8{};
+                if (SEAM && cg == 1 && ((KX == 0 && seam_l) || (KX == 2 && seam_r))) x[cg] = bf16x8{};
             }
         };
         auto ldw = [&](int frag) { return *reinterpret_cast<const bf16x8*>(ws + frag * 1024 + lane * 16); };
@@ -473,6 +478,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                 const int off = (KX == 0 && cg == 0) ? off_l : (KX == 2 && cg == 2) ? off_r : offk[KX];
                 x[cg] = *reinterpret_cast<const bf16x8*>(rb + cg * 1024 + off);
                 if ((KX == 0 && cg == 0 && edge_l) || (KX == 2 && cg == 2 && edge_r)) x[cg] = bf16x8{};
+                if (SEAM && cg == 1 && ((KX == 0 && seam_l) || (KX == 2 && seam_r))) x[cg] = bf16x8{};
             }
         };
         auto ldw = [&](int frag) { return *reinterpret_cast<const bf16x8*>(ws + frag * 1024 + lane * 16); };
@@ -702,6 +708,7 @@ constexpr int C1_WBYTES = 2 * 9 * 2 * 1024;
 constexpr int C1_LDS = C1_NSB * C1_STGB + C1_WBYTES + 32 * 4;
 static_assert(C1_LDS <= 160 * 1024, "LDS budget");
 
+template <bool SEAM>
 __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4) conv1_stream_kernel(Conv1Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const stg = smem;
@@ -815,6 +822,7 @@ __global__ void __launch_bounds__((NCOMP + NLOAD) * 64, (NCOMP + NLOAD + 3) / 4)
                         const int off = (kx == 0 && cg == 0) ? off_l : (kx == 2 && cg == 2) ? off_r : offk[kx];
                         bf16x8 x = *reinterpret_cast<const bf16x8*>(sb + ky * ROWB + cg * 1024 + off);
                         if ((kx == 0 && cg == 0 && edge_l) || (kx == 2 && cg == 2 && edge_r)) x = bf16x8{};
+                        if (SEAM && cg == 1 && ((kx == 0 && px == 8) || (kx == 2 && px == 7))) x = bf16x8{};      // two 24-pixel images per row: see chain2_kernel
 #pragma unroll
                         for (int n = 0; n < 2; ++n) acc[n][cg] = mma16(wf[ky][n], x, acc[n][cg]);
                     }
@@ -852,10 +860,20 @@ uint16_t bf16_host(float f) {
 }
 
 template <int EXT, int NB0, int NB1, int MODE>
-int launch_chain(sr_ctx* ctx, const ChainParams& p, bool has_o, int nwg, hipStream_t st) {
+int launch_chain(sr_ctx* ctx, const ChainParams& p, bool has_o, int nwg, bool seam, hipStream_t st) {
     constexpr int lds = ChainLds<NB0, NB1, MODE>::BYTES;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (p.dbg) {                                  // diagnostic stamped variant (never in production)
+    if (seam) {                                   // two 24-pixel-wide images per row
+        if (has_o) {
+            auto k = chain2_kernel<EXT, NB0, NB1, MODE, true, false, true>;
+            if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), lds)) return rc;
+            hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), lds, st, p);
+        } else {
+            auto k = chain2_kernel<EXT, NB0, NB1, MODE, false, false, true>;
+            if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), lds)) return rc;
+            hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), lds, st, p);
+        }
+    } else if (p.dbg) {                                  // diagnostic stamped variant (never in production)
         auto k = chain2_kernel<EXT, NB0, NB1, MODE, MODE == 1, true>;
         if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), lds)) return rc;
         ChainParams q = p;
@@ -929,7 +947,7 @@ bool conv1_stream_supported(const ConvWeights& w, const TensorView& in, int W) {
            in.coff == 0 && in.cs % 32 == 0 && in.cs >= 96;
 }
 
-int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st) {
+int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st, bool seam) {
     if (!conv1_stream_supported(w, in, W)) return ctx->fail(SR_ERR_INVALID, "streaming conv1: needs a 64 -> 32 bf16 3x3 conv on a 48-pixel-wide row-blocked buffer");
     if (B <= 0 || H <= 0) return ctx->fail(SR_ERR_INVALID, "streaming conv1: empty tensor");
     if (!ctx->zero_page) return ctx->fail(SR_ERR_STATE, "context has no zero page");      // sr_init allocates and clears it
@@ -950,7 +968,7 @@ int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B,
         const double px = (double)B * H * W;
         rec = ctx->prof_open("dense_conv1_stream<bf16,64->32>", 2.0 * px * 9.0 * 64 * 32, px * 2.0 * (64 + 32), st);
     }
-    auto k = conv1_stream_kernel;
+    auto k = seam ? conv1_stream_kernel<true> : conv1_stream_kernel<false>;
     if (int rc = ctx->ensure_dyn_lds(reinterpret_cast<const void*>(k), C1_LDS)) return rc;
     hipLaunchKernelGGL(k, dim3(nwg), dim3((NCOMP + NLOAD) * 64), C1_LDS, st, p);
     ctx->prof_close(rec, st);
@@ -965,7 +983,7 @@ bool chain_supported(const ChainWeights& w, const TensorView& in, int W) {
 // in: the dense block's row-blocked concat buffer.  tail (nb1 == 4): out = alpha*(conv_b + bias) + beta_x * x + beta_o * skip_o into channels
 // [0,64) of `out` (x = channels [0,64) of `in`).  Otherwise both convs are growth convs writing chunks ext and ext+1 of `in`.
 int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H, int W, TensorView out, TensorView skip_o, float alpha,
-                 float beta_x, float beta_o, hipStream_t st) {
+                 float beta_x, float beta_o, hipStream_t st, bool seam) {
     if (!chain_supported(w, in, W)) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: needs W == 48 and a row-blocked source buffer");
     if (B <= 0 || H <= 0) return ctx->fail(SR_ERR_INVALID, "fused dense-block pair: empty tensor");
     const bool tail = w.nb1 == 4;
@@ -1019,9 +1037,9 @@ int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H
     }
     int rc;
     const bool has_o = skip_o.p != nullptr;
-    if (tail && w.ext == 5 && w.nb0 == 2) rc = launch_chain<5, 2, 4, 1>(ctx, p, has_o, nwg, st);
-    else if (!tail && w.ext == 2 && w.nb0 == 2 && w.nb1 == 2) rc = launch_chain<2, 2, 2, 0>(ctx, p, false, nwg, st);
-    else if (!tail && w.ext == 3 && w.nb0 == 2 && w.nb1 == 2) rc = launch_chain<3, 2, 2, 0>(ctx, p, false, nwg, st);
+    if (tail && w.ext == 5 && w.nb0 == 2) rc = launch_chain<5, 2, 4, 1>(ctx, p, has_o, nwg, seam, st);
+    else if (!tail && w.ext == 2 && w.nb0 == 2 && w.nb1 == 2) rc = launch_chain<2, 2, 2, 0>(ctx, p, false, nwg, seam, st);
+    else if (!tail && w.ext == 3 && w.nb0 == 2 && w.nb1 == 2) rc = launch_chain<3, 2, 2, 0>(ctx, p, false, nwg, seam, st);
     else rc = ctx->fail(SR_ERR_INVALID, "fused dense-block pair: shape not instantiated");
     ctx->prof_close(rec, st);
     return rc;

@@ -493,6 +493,57 @@ int nhwc_to_blocked_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src
     return SR_OK;
 }
 
+// Two-up packing of 24-pixel-wide images for the fused dense-block kernels (round 4; dense_fused.hip SEAM): image b sits in columns [24 (b & 1), 24 (b & 1) + 24) of
+// image b >> 1 of a row-blocked buffer of 48-pixel rows, [ceil(B / 2)][H][dst_C / 32][48][32].  pack: NHWC channels -> packed (an odd batch's missing half is written
+// as zeros); unpack: packed -> the ordinary row-blocked layout [B][H][dst_C / 32][W][32].  bf16, 32-channel granularity, one 16-byte unit per thread.
+__global__ void pack_pairs_kernel(const bf16_t* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, bf16_t* dst, int64_t dst_C, int dst_coff) {
+    const int Bp = (B + 1) & ~1;
+    const int64_t n = (int64_t)Bp * H * (C / 32) * W * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(i & 3);
+        int64_t t = i >> 2;
+        const int x = (int)(t % W); t /= W;
+        const int cb = (int)(t % (C / 32)); t /= (C / 32);
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        bf16x8 v = {};
+        if (b < B) v = *reinterpret_cast<const bf16x8*>(src + (((int64_t)b * H + y) * W + x) * src_cs + src_coff + cb * 32 + sl * 8);
+        *reinterpret_cast<bf16x8*>(dst + ((int64_t)(b >> 1) * H + y) * (2 * W) * dst_C + (int64_t)(dst_coff / 32 + cb) * (2 * W) * 32 + ((b & 1) * W + x) * 32 + sl * 8) = v;
+    }
+}
+
+__global__ void unpack_pairs_kernel(const bf16_t* src, int64_t src_C, int src_coff, int B, int H, int W, int C, bf16_t* dst, int64_t dst_C, int dst_coff) {
+    const int64_t n = (int64_t)B * H * (C / 32) * W * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(i & 3);
+        int64_t t = i >> 2;
+        const int x = (int)(t % W); t /= W;
+        const int cb = (int)(t % (C / 32)); t /= (C / 32);
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + ((int64_t)(b >> 1) * H + y) * (2 * W) * src_C + (int64_t)(src_coff / 32 + cb) * (2 * W) * 32 + ((b & 1) * W + x) * 32 + sl * 8);
+        *reinterpret_cast<bf16x8*>(dst + ((int64_t)b * H + y) * W * dst_C + (int64_t)(dst_coff / 32 + cb) * W * 32 + x * 32 + sl * 8) = v;
+    }
+}
+
+int pack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, hipStream_t st) {
+    if (C % 32 || src_coff % 8 || dst_coff % 32 || dst_C % 32 || src_cs % 8) return ctx->fail(SR_ERR_INVALID, "pack_pairs: 32-channel granularity");
+    const int64_t n = (int64_t)((B + 1) & ~1) * H * (C / 32) * W * 4;
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(pack_pairs_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const bf16_t*>(src), src_cs, src_coff, B, H, W, C, static_cast<bf16_t*>(dst), dst_C, dst_coff);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int unpack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_C, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, hipStream_t st) {
+    if (C % 32 || src_coff % 32 || dst_coff % 32 || dst_C % 32 || src_C % 32) return ctx->fail(SR_ERR_INVALID, "unpack_pairs: 32-channel granularity");
+    const int64_t n = (int64_t)B * H * (C / 32) * W * 4;
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(unpack_pairs_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const bf16_t*>(src), src_C, src_coff, B, H, W, C, static_cast<bf16_t*>(dst), dst_C, dst_coff);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
 // Diagnostic tap (sr_model_set_tap): channels [coff, coff + C) of an activation buffer -- NHWC or row-blocked, bf16 or fp32 -- as a dense
 // fp32 NHWC tensor.  One thread per element; never on a timed path.
 __global__ void tap_copy_kernel(const void* src, int dtype, int blk, int64_t cs, int coff, int64_t rows, int W, int C, float* dst) {

@@ -125,3 +125,85 @@ def test_fused_tail_exact_integers(fused_ctx):
     for n, ref in (("rrdb_0_dense1_conv2", feats[2]), ("rrdb_0_dense1_conv3", round_to_bf16(feats[3].astype(np.float32)).astype(np.float64))):
         assert np.array_equal(t1[n].float().cpu().numpy().astype(np.float64), ref), n
         assert np.array_equal(t0[n].float().cpu().numpy().astype(np.float64), ref), n
+
+
+# ---- 24-pixel-wide patches, two per 48-pixel row (round 4: api.hip pack2, dense_fused.hip SEAM; patch_size_lr = 24 is the reference's own training patch,
+# ESRGAN_model.py:858 / constants.py:8) ----
+
+PAIR_CASES = [
+    # B, H, grid cap
+    (8, 24, 0),      # the patch shape, an even batch
+    (7, 24, 2),      # an odd batch: the last row pair's right half is padding
+    (2, 24, 0),      # one packed image
+    (5, 9, 3),       # height not a multiple of the step, ranges cutting packed images
+    (12, 5, 4),
+    (3, 1, 0),       # one-row images
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_two_up_packed_24_wide_patches_match_layer_by_layer_and_oracle(fused_ctx, case):
+    """The fused dense-block kernels on 24-pixel-wide images: two images side by side per 48-pixel row, columns 23 | 24 an image border.  Against the layer-by-layer
+    path (same graph, tile kernels) and the bf16-storage oracle; the seam is where a mistake would show (a conv reading across it mixes two images)."""
+    ctx = fused_ctx
+    B, H, cap = case
+    nb = 2
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, num_blocks=nb, growth_channels=32, use_attention=False, ctx=ctx)
+    w = bf16_rounded(init_weights(m.layer_shapes(), seed=3500))
+    m.set_weights(w)
+    x = round_to_bf16(np.random.default_rng(B * 10 + H).uniform(-1, 1, (B, H, 24, 3)).astype(np.float32))
+    xd = ctx.to_device(x, torch.bfloat16)
+    dense = ctx.FUSED_ALL & ~35
+    ctx.set_fused(dense, 0)
+    ctx.profile_begin()
+    y0 = m.forward(xd)
+    k0 = {r["kernel"] for r in ctx.profile_end()}
+    ctx.set_fused(ctx.FUSED_ALL, cap)
+    ctx.profile_begin()
+    y1 = m.forward(xd)
+    k1 = {r["kernel"] for r in ctx.profile_end()}
+    assert not any(k.startswith("dense_") for k in k0), k0
+    assert {"dense_tail_fused<bf16,conv4+conv5>", "dense_pair_fused<bf16>", "dense_conv1_stream<bf16,64->32>"} <= k1, k1       # the fused kernels ran on the 24-wide batch
+    assert not any(k.startswith("conv_rows<bf16,k3,kg1,nt2>") for k in k1), k1                                                   # ... and no dense-block conv ran on the tile kernel
+    assert torch.equal(y1, m.forward(xd))
+    ref = M.esrgan_g_forward(x, w, 2, nb, dtype=np.float64, attention=False, bf16_storage=True)
+    a, b = y0.float().cpu().numpy(), y1.float().cpu().numpy()
+    assert a.shape == ref.shape == (B, 2 * H, 48, 3)
+    e0, e1 = rel_l2(a, ref), rel_l2(b, ref)
+    assert e1 <= 5e-3 and e1 <= 2.0 * e0 + 1e-3, (e0, e1)
+    assert rel_l2(b, a) <= 5e-3
+    # per image and per column: no image, and no column next to the seam or a border, stands out (a seam mistake would put its error into HR columns 44-51)
+    err = np.abs(b - ref).max(axis=(1, 3))                                   # [B, HR columns]
+    assert err.max() <= 16.0 * max(np.median(err), 2.0 ** -9), (float(err.max()), float(np.median(err)), np.unravel_index(err.argmax(), err.shape))
+    # an image is the same whatever it is paired with, and whichever half of a row it rides in
+    if B >= 3:
+        perm = [1, 0] + list(range(2, B))
+        y2 = m.forward(ctx.to_device(x[perm], torch.bfloat16))
+        assert torch.equal(y2[0], y1[1]) and torch.equal(y2[1], y1[0])
+        y3 = m.forward(ctx.to_device(x[1:], torch.bfloat16))                 # every image moves to the other half, with another partner
+        assert torch.equal(y3, y1[1:])
+    # taps switch the packing off (they need the plain layout): same numbers as the layer-by-layer path's taps
+    yt, t = m.forward_with_taps(xd, ["rrdb_0_dense1_conv5"])
+    assert t["rrdb_0_dense1_conv5"].shape == (B, H, 24, 64)
+
+
+def test_two_up_packing_through_the_wrapper(ctx):
+    """ESRGAN.super_resolve_image(patch_size_lr=24) in bf16: the packed path inside the reference's patch plumbing, against the oracle's patch-mode image."""
+    from oracle import ops as O
+    from sr355.synth import make_pairs
+    from sr355.weights import condition_attention
+    from SRModels.deep_learning_models.ESRGAN_model import ESRGAN
+    m = ESRGAN(compute_dtype="bf16")
+    m.setup_model(scale_factor=2, growth_channels=32, num_rrdb_blocks=2)
+    w = bf16_rounded(condition_attention(init_weights(m.generator.layer_shapes(), seed=3600)))
+    m.set_weights(w)
+    lr, hr = make_pairs(1, 60, 52, 2, seed=11)
+    ctx.profile_begin()
+    sr, _ = m.super_resolve_image(lr[0], patch_size_lr=24, stride=12, batch_size=64)
+    ks = {r["kernel"] for r in ctx.profile_end()}
+    assert "dense_tail_fused<bf16,conv4+conv5>" in ks, ks
+    ref = M.esrgan_super_resolve(lr[0], w, 2, 24, 12, num_rrdb=2, dtype=np.float64)
+    assert sr.shape == ref.shape == (120, 104, 3)
+    assert np.abs(sr - ref).max() <= 3e-2
+    d = abs(float(O.psnr(hr[0], sr, dtype=np.float64)) - float(O.psnr(hr[0], np.clip(ref, 0, 1), dtype=np.float64)))
+    assert d <= 0.01, d
