@@ -884,8 +884,12 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
     const bool use_cells = m->taps.empty() && (ctx->chain_mask & 16) != 0;
     // 24-pixel-wide patches (patch_size_lr = 24: the reference's own training patch, ESRGAN_model.py:858 / constants.py:8) through the fused dense-block kernels, which are
     // built for 48-pixel rows: two images side by side per row, [ceil(B / 2)][H][C / 32][48][32], from the trunk's first concat buffer to trunk_conv's input; the kernels
-    // treat columns 23 | 24 as an image border (dense_fused.hip SEAM).  Needs all three fused dense-block kernels (mask bits 0, 1, 5) and no taps.
-    const bool pack2 = m->kind == SR_MODEL_ESRGAN_G && m->T == SR_DTYPE_BF16 && W == 24 && m->taps.empty() && (ctx->chain_mask & 35) == 35 && !m->chains.empty() && B >= 2;
+    // treat columns 23 | 24 as an image border (dense_fused.hip SEAM).  Needs all three fused dense-block kernels (mask bits 0, 1, 5); taps read the packed buffers through tap_copy's pair mapping.
+    bool pack2 = m->kind == SR_MODEL_ESRGAN_G && m->T == SR_DTYPE_BF16 && W == 24 && (ctx->chain_mask & 35) == 35 && !m->chains.empty() && B >= 2;
+    for (const auto& tp : m->taps) {                                          // a tap on a tail pair's first conv makes that pair run layer by layer (below), which the packed layout cannot
+        const Op& to = m->ops[tp.first];
+        if (to.kind == OP_CONV && to.chain >= 0 && m->chains[to.chain].tail && to.chain_pos == 0) pack2 = false;
+    }
     int rc = ensure_workspace(m, pack2 ? (B + 1) & ~1 : B, H, W, st, use_cells);
     if (rc) return rc;
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
@@ -1061,7 +1065,7 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 buf_hw(m->bufs[top.out.buf], H, W, &th, &tw);
                 if (it->second.cap < (int64_t)B * th * tw * C_) return ctx->fail(SR_ERR_CAPACITY, "tap buffer too small");
                 const BufSpec& ob = m->bufs[top.out.buf];
-                rc = tap_copy_launch(ctx, m->bufp[top.out.buf], T, ob.blk, ob.Cbuf, top.out.coff, B, th, tw, C_, it->second.dst, st);
+                rc = tap_copy_launch(ctx, m->bufp[top.out.buf], T, ob.blk, ob.Cbuf, top.out.coff, B, th, tw, C_, it->second.dst, st, pack2 && ob.blk);
                 if (rc) return rc;
             }
         }

@@ -230,7 +230,7 @@ int attention_launch(sr_ctx* ctx, int dtype, const void* qkv, int64_t cs, int qo
 int nhwc_to_blocked_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C,
                            int dst_coff, hipStream_t st);
 int clock_probe_launch(sr_ctx* ctx, float* mhz_out, hipStream_t st);
-int tap_copy_launch(sr_ctx* ctx, const void* src, int dtype, int blk, int64_t cs, int coff, int B, int H, int W, int C, float* dst, hipStream_t st);
+int tap_copy_launch(sr_ctx* ctx, const void* src, int dtype, int blk, int64_t cs, int coff, int B, int H, int W, int C, float* dst, hipStream_t st, bool pairs = false);
 int convert_pad_launch(sr_ctx* ctx, const void* x, int in_dtype, int64_t npix, int C, void* y, int out_dtype,
                        int Cp, float mul, float add, hipStream_t st);
 int maxpool2_launch(sr_ctx* ctx, int dtype, const void* x, int B, int H, int W, int C, int64_t x_cs, void* y,

@@ -546,23 +546,31 @@ int unpack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_C, int src_cof
 
 // Diagnostic tap (sr_model_set_tap): channels [coff, coff + C) of an activation buffer -- NHWC or row-blocked, bf16 or fp32 -- as a dense
 // fp32 NHWC tensor.  One thread per element; never on a timed path.
-__global__ void tap_copy_kernel(const void* src, int dtype, int blk, int64_t cs, int coff, int64_t rows, int W, int C, float* dst) {
+__global__ void tap_copy_kernel(const void* src, int dtype, int blk, int64_t cs, int coff, int64_t rows, int W, int C, float* dst, int pair_h) {
     const int64_t n = rows * W * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int64_t pix = i / C;
-        const int x = (int)(pix % W);
-        const int64_t row = pix / W;
+        int x = (int)(pix % W);
+        int64_t row = pix / W;
+        int Wb = W;
+        if (pair_h) {                                          // two-up packed buffer (pack_pairs_kernel): image b = row / H rides in half b & 1 of packed image b >> 1
+            const int64_t b = row / pair_h;
+            row = (b >> 1) * pair_h + row % pair_h;
+            x += (int)(b & 1) * W;
+            Wb = 2 * W;
+        }
         const int ch = coff + c;
-        const int64_t e = blk ? row * W * cs + (int64_t)(ch >> 5) * W * 32 + x * 32 + (ch & 31) : pix * cs + ch;
+        const int64_t e = blk ? row * Wb * cs + (int64_t)(ch >> 5) * Wb * 32 + x * 32 + (ch & 31) : pix * cs + ch;
         dst[i] = dtype == SR_DTYPE_BF16 ? (float)static_cast<const bf16_t*>(src)[e] : static_cast<const float*>(src)[e];
     }
 }
 
-int tap_copy_launch(sr_ctx* ctx, const void* src, int dtype, int blk, int64_t cs, int coff, int B, int H, int W, int C, float* dst, hipStream_t st) {
+int tap_copy_launch(sr_ctx* ctx, const void* src, int dtype, int blk, int64_t cs, int coff, int B, int H, int W, int C, float* dst, hipStream_t st, bool pairs) {
+    if (pairs && !blk) return ctx->fail(SR_ERR_STATE, "tap: two-up packing is a row-blocked layout");
     const int64_t n = (int64_t)B * H * W * C;
     if (n <= 0) return SR_OK;
-    hipLaunchKernelGGL(tap_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, src, dtype, blk, cs, coff, (int64_t)B * H, W, C, dst);
+    hipLaunchKernelGGL(tap_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, src, dtype, blk, cs, coff, (int64_t)B * H, W, C, dst, pairs ? H : 0);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;
 }

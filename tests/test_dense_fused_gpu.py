@@ -175,16 +175,33 @@ def test_two_up_packed_24_wide_patches_match_layer_by_layer_and_oracle(fused_ctx
     # per image and per column: no image, and no column next to the seam or a border, stands out (a seam mistake would put its error into HR columns 44-51)
     err = np.abs(b - ref).max(axis=(1, 3))                                   # [B, HR columns]
     assert err.max() <= 16.0 * max(np.median(err), 2.0 ** -9), (float(err.max()), float(np.median(err)), np.unravel_index(err.argmax(), err.shape))
-    # an image is the same whatever it is paired with, and whichever half of a row it rides in
-    if B >= 3:
-        perm = [1, 0] + list(range(2, B))
+    # an image does not depend on its partner or on where its pair sits in the stream: bit for bit.  Which HALF it rides in may flip the last bf16 bit of a few values:
+    # the RRDB's outer skip joins column group kx's accumulators behind ring granule kx (chain2_kernel, so_fetch), so the fp32 summation order differs between column
+    # groups -- in the 48-wide layout just the same (tools/probe_pack.py: one value of rrdb_0_dense3_conv5 in 36 864, -0.18652 | -0.1875, fp32 sums either side of a tie).
+    if B >= 4:
+        perm = [2, 3, 0, 1] + list(range(4, B))
         y2 = m.forward(ctx.to_device(x[perm], torch.bfloat16))
-        assert torch.equal(y2[0], y1[1]) and torch.equal(y2[1], y1[0])
+        assert torch.equal(y2[:2], y1[2:4]) and torch.equal(y2[2:4], y1[:2])
+        xs = x.copy()
+        xs[0] = x[B - 1]                                                     # image 1 keeps its half and gets another partner
+        y4 = m.forward(ctx.to_device(xs, torch.bfloat16))
+        assert torch.equal(y4[1:B - 1], y1[1:B - 1])
+    if B >= 3:
         y3 = m.forward(ctx.to_device(x[1:], torch.bfloat16))                 # every image moves to the other half, with another partner
-        assert torch.equal(y3, y1[1:])
-    # taps switch the packing off (they need the plain layout): same numbers as the layer-by-layer path's taps
-    yt, t = m.forward_with_taps(xd, ["rrdb_0_dense1_conv5"])
-    assert t["rrdb_0_dense1_conv5"].shape == (B, H, 24, 64)
+        d = (y3.float() - y1[1:].float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 and float(d.mean()) <= 2.0 ** -13, (float(d.max()), float(d.mean()))
+    # taps read the packed buffers through tap_copy's pair mapping: same output, and the tapped tensors agree with the layer-by-layer path's
+    names = ["rrdb_0_dense1_conv1", "rrdb_0_dense1_conv3", "rrdb_0_dense1_conv5", f"rrdb_{nb - 1}_dense3_conv5", "trunk_conv"]
+    ctx.profile_begin()
+    yt, t1 = m.forward_with_taps(xd, names)
+    assert "dense_tail_fused<bf16,conv4+conv5>" in {r["kernel"] for r in ctx.profile_end()}
+    assert torch.equal(yt, y1)
+    ctx.set_fused(dense, 0)
+    _, t0 = m.forward_with_taps(xd, names)
+    for n in names:
+        assert t1[n].shape == t0[n].shape
+        assert rel_l2(t1[n].cpu().numpy(), t0[n].cpu().numpy()) <= 5e-3, n
+    assert float((t1["rrdb_0_dense1_conv1"] - t0["rrdb_0_dense1_conv1"]).abs().max()) <= 2.0 ** -7         # one conv on identical inputs: fp32 order apart, a last bf16 bit here and there
 
 
 def test_two_up_packing_through_the_wrapper(ctx):
