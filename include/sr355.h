@@ -98,7 +98,7 @@ int  sr_debug_set_chain_stamp_buffer(sr_ctx* ctx, void* device_u64_buffer, int64
  * which = 1 -> the fused dense-block kernels (fixed size; `workgroups` ignored).  Pure function, no context; -1 for anything else. */
 int64_t sr_debug_stamp_bytes_needed(int which, int64_t workgroups);
 /* Which dense-block conv pairs of the ESRGAN trunk run as one fused line-buffer kernel when the shape allows (bf16, 32 growth
- * channels, 48-pixel-wide images): bit 0 = conv4+conv5, bit 1 = conv2+conv3; bit 2 = the generator's last conv (64 -> image channels,
+ * channels, images 48 pixels wide, or 24 wide with two images per 48-pixel row when bits 0, 1 and 5 are all set): bit 0 = conv4+conv5, bit 1 = conv2+conv3; bit 2 = the generator's last conv (64 -> image channels,
  * ESRGAN_model.py:341) computed inside final_conv1's epilogue, so that final_conv1's 64-channel output is never stored; bit 3 = the three
  * 1x1 projections that open a SelfAttention layer (ESRGAN_model.py:48-56) computed in the epilogue of the conv producing its input; bit 4 = batches of small
  * images (the VGG16 classifier's block 5: 6 x 6 pixels for 96-pixel patches) packed side by side with zero separator rows / columns into one
@@ -217,6 +217,13 @@ int  sr_conv2d_dev_views(sr_ctx* ctx, const sr_view* x, int B, int H, int W, int
 int  sr_conv2d_wgrad_views(sr_ctx* ctx, const sr_view* x, const sr_view* dy, int B, int H, int W, int Cin, int Cout, int K,
                            float* dw_hwio, float* db, void* stream);
 int  sr_eltwise_views(sr_ctx* ctx, int op, const sr_view* a, const sr_view* b, float alpha, float beta, const sr_view* out, int64_t npix, int C, void* stream);
+/* Pack the weights of n conv uses by ONE launch, now, on `stream`, from the current contents of w / bias (a training step otherwise packs once per sr_conv2d_dev /
+ * _views call: ~800 launches of ~5 us in the step of ESRGAN_model.py:475-533).  A later sr_conv2d_dev / sr_conv2d_dev_views on this context whose (d_w, d_bias, K, Cin,
+ * Cout, rot) equals a listed use takes the pack made here instead of packing again; Cin / Cout are those of the CALL (for rot = 1, the gradient's channels in, the
+ * layer's input channels out).  Every call replaces the whole list; n = 0 forgets it.  The caller must call again after changing any listed weight (a trainer: at the
+ * start of every step) -- the library cannot see a write to w. */
+typedef struct { const float* w; const float* bias; int32_t K, Cin, Cout, rot; } sr_pack_desc;
+int  sr_conv_prepack(sr_ctx* ctx, const sr_pack_desc* uses, int n, void* stream);
 int  sr_eltwise(sr_ctx* ctx, int op, const void* a, const void* b, float alpha, float beta, void* out, int64_t n, void* stream);
 /* keras.optimizers.Adam's dense update (the optimiser of ESRGAN_model.py:176-195, SRCNN_model.py:55-60, EDSR_model.py:127-140) over one flat
  * fp32 bucket of n parameters, in place on the device: g is first multiplied by grad_scale (1 / world size after a summing all-reduce; 1 leaves

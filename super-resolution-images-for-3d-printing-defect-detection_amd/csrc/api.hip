@@ -1164,6 +1164,13 @@ int sr_conv2d_dev_views(sr_ctx* ctx, const sr_view* x, int B, int H, int W, int 
     return conv_launch(ctx, cw, TensorView{x->p, x->cs, x->coff}, B, H, W, TensorView{y->p, y->cs, y->coff}, ep, st);
 }
 
+int sr_conv_prepack(sr_ctx* ctx, const sr_pack_desc* uses, int n, void* stream) {
+    DeviceGuard dg_(ctx);
+    if (!ctx) return SR_ERR_INVALID;
+    if (n < 0 || (n > 0 && !uses)) { ctx->pack_cache.clear(); return ctx->fail(SR_ERR_INVALID, "conv prepack: bad list"); }
+    return conv_prepack_dev(ctx, uses, n, static_cast<hipStream_t>(stream));
+}
+
 int sr_conv2d_wgrad_views(sr_ctx* ctx, const sr_view* x, const sr_view* dy, int B, int H, int W, int Cin, int Cout, int K, float* dw_hwio, float* db, void* stream) {
     DeviceGuard dg_(ctx);
     if (!ctx) return SR_ERR_INVALID;

@@ -52,6 +52,20 @@ struct sr_ctx {
     Arena attn_kn;                // attention: per-key-group largest key norm (stream-ordered reuse)
     Arena dev_w, dev_b, dev_x;    // sr_conv2d_dev: packed weights / padded bias / padded input of the call in flight (stream-ordered reuse)
     void* arena(Arena& a, size_t bytes, hipStream_t st);   // grow-only; growing waits for `st` first
+    // sr_conv_prepack: packed fp32 weights of a list of conv uses, written by one launch and found again by conv_pack_weights_dev
+    struct PackKey {
+        const void* w; const void* b; int K, Cin, Cout, rot;
+        bool operator==(const PackKey& o) const { return w == o.w && b == o.b && K == o.K && Cin == o.Cin && Cout == o.Cout && rot == o.rot; }
+    };
+    struct PackKeyHash {
+        size_t operator()(const PackKey& k) const {
+            return std::hash<const void*>()(k.w) ^ (std::hash<const void*>()(k.b) * 31u) ^ ((size_t)k.rot << 1) ^ ((size_t)k.Cin << 20) ^ ((size_t)k.Cout << 36) ^ ((size_t)k.K << 52);
+        }
+    };
+    std::unordered_map<PackKey, std::pair<void*, float*>, PackKeyHash> pack_cache;
+    Arena pack_w, pack_b, pack_tab;
+    std::vector<char> pack_tab_host;     // the job table as last uploaded
+    void* pack_tab_dev = nullptr;
     static constexpr int ZERO_PAGE_BYTES = 32768;
     void* zero_page = nullptr;    // ZERO_PAGE_BYTES of zeros (DMA source of padding rows / halo pixels in dense_fused.hip, conv_stream.hip): allocated and cleared
                                   // synchronously in sr_init, so that no launch on any stream can see it before it is zero
@@ -173,6 +187,7 @@ struct ConvEpilogue {
 // 180-degree-rotated, channel-swapped form is wanted ([K,K,Cout,Cin]: the input-gradient conv of that layer); weights and bias land in
 // the context's arenas (valid until the next sr_conv2d_dev on the stream)
 int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias, int KS, int Cin, int Cout, int rot, ConvWeights* out, hipStream_t st);
+int conv_prepack_dev(sr_ctx* ctx, const sr_pack_desc* descs, int n, hipStream_t st);
 // rows_head = 1 (bf16 3x3 only): a conv whose Cin fits one 16-byte slice (an RGB head) is packed for the row-sliding kernel on one
 // zero-padded 32-channel chunk instead of the thin kernel -- the caller then provides a 32-channel input view
 int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS, int Cin, int Cout,

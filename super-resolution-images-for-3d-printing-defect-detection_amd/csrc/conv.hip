@@ -774,43 +774,75 @@ int conv_pack_weights(sr_ctx* ctx, const float* hwio, const float* bias, int KS,
 }
 
 // ---- device-side packing (fp32): one thread per packed element decodes its (tap, cin, cout) exactly as the host loops above
-__global__ void pack_weights_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int layout, int ntap, int Cin, int Cout,
-                                        int CinP, int NT, int nchunks, int KGPT, int rot, const float* __restrict__ bias, float* __restrict__ bias_out, int CoutP) {
-    // the zero-padded bias rides along (block 0): one launch per conv use less than a separate pad kernel
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < CoutP; i += blockDim.x) bias_out[i] = (bias && i < Cout) ? bias[i] : 0.f;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-        int tap, ci, co;
-        if (layout == 0) {                        // few: [tap][CinP][4]
-            co = (int)(idx & 3);
-            const int64_t t = idx >> 2;
-            ci = (int)(t % CinP); tap = (int)(t / CinP);
-        } else if (layout == 1) {                 // thin: [ct][g][n][lane][j], E = 4
-            const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-            int64_t t = idx >> 8;
-            const int nn = (int)(t % NT); t /= NT;
-            const int g = (int)(t % nchunks), ct = (int)(t / nchunks);          // nchunks = KGT
-            tap = 2 * g + (lane >> 5); ci = j; co = (ct * NT + nn) * 32 + (lane & 31);
-        } else {                                  // wide: [ct][ch][tap][kg][n][lane][j], E = 4
-            const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-            int64_t t = idx >> 8;
-            const int nn = (int)(t % NT); t /= NT;
-            const int kg = (int)(t % KGPT); t /= KGPT;
-            tap = (int)(t % ntap); t /= ntap;
-            const int ch = (int)(t % nchunks), ct = (int)(t / nchunks);
-            ci = ch * (KGPT * 8) + kg * 8 + (lane >> 5) * 4 + j; co = (ct * NT + nn) * 32 + (lane & 31);
-        }
-        float v = 0.f;
-        if (tap < ntap && ci < Cin && co < Cout)
-            v = rot ? src[((int64_t)(ntap - 1 - tap) * Cout + co) * Cin + ci] : src[((int64_t)tap * Cin + ci) * Cout + co];
-        dst[idx] = v;
+struct PackPlan { int layout, ntap, Cin, Cout, CinP, NT, nchunks, KGPT, rot, CoutP; };
+
+static __device__ __forceinline__ float pack_element_f32(const float* __restrict__ src, int64_t idx, const PackPlan& q) {
+    int tap, ci, co;
+    if (q.layout == 0) {                          // few: [tap][CinP][4]
+        co = (int)(idx & 3);
+        const int64_t t = idx >> 2;
+        ci = (int)(t % q.CinP); tap = (int)(t / q.CinP);
+    } else if (q.layout == 1) {                   // thin: [ct][g][n][lane][j], E = 4
+        const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        int64_t t = idx >> 8;
+        const int nn = (int)(t % q.NT); t /= q.NT;
+        const int g = (int)(t % q.nchunks), ct = (int)(t / q.nchunks);          // nchunks = KGT
+        tap = 2 * g + (lane >> 5); ci = j; co = (ct * q.NT + nn) * 32 + (lane & 31);
+    } else {                                      // wide: [ct][ch][tap][kg][n][lane][j], E = 4
+        const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        int64_t t = idx >> 8;
+        const int nn = (int)(t % q.NT); t /= q.NT;
+        const int kg = (int)(t % q.KGPT); t /= q.KGPT;
+        tap = (int)(t % q.ntap); t /= q.ntap;
+        const int ch = (int)(t % q.nchunks), ct = (int)(t / q.nchunks);
+        ci = ch * (q.KGPT * 8) + kg * 8 + (lane >> 5) * 4 + j; co = (ct * q.NT + nn) * 32 + (lane & 31);
     }
+    float v = 0.f;
+    if (tap < q.ntap && ci < q.Cin && co < q.Cout)
+        v = q.rot ? src[((int64_t)(q.ntap - 1 - tap) * q.Cout + co) * q.Cin + ci] : src[((int64_t)tap * q.Cin + ci) * q.Cout + co];
+    return v;
 }
 
-int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias, int KS, int Cin, int Cout, int rot, ConvWeights* out, hipStream_t st) {
+__global__ void pack_weights_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, PackPlan q, const float* __restrict__ bias, float* __restrict__ bias_out) {
+    // the zero-padded bias rides along (block 0): one launch per conv use less than a separate pad kernel
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < q.CoutP; i += blockDim.x) bias_out[i] = (bias && i < q.Cout) ? bias[i] : 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) dst[idx] = pack_element_f32(src, idx, q);
+}
+
+// Many convs' weights by ONE launch (sr_conv_prepack: a training step's ~800 per-use packs were 3.9 ms of 4.9-us launches): job j owns blocks [blk0, next job's blk0),
+// PACK_JOB_ELEMS packed elements per block; a block finds its job by bisection of the table.
+constexpr int PACK_JOB_ELEMS = 2048;
+struct PackJob { const float* src; const float* bias; float* dst; float* bias_out; int64_t n; PackPlan q; int blk0; int pad_; };
+
+__global__ void __launch_bounds__(256) pack_weights_f32_many_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob& jb = jobs[lo];
+    const PackPlan q = jb.q;
+    const int lb = (int)blockIdx.x - jb.blk0;
+    const float* __restrict__ src = jb.src;
+    float* __restrict__ dst = jb.dst;
+    const int64_t n = jb.n;
+    if (lb == 0) {
+        const float* bias = jb.bias;
+        float* bo = jb.bias_out;
+        for (int i = threadIdx.x; i < q.CoutP; i += 256) bo[i] = (bias && i < q.Cout) ? bias[i] : 0.f;
+    }
+    const int64_t base = (int64_t)lb * PACK_JOB_ELEMS;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < PACK_JOB_ELEMS; i += 256)
+        if (base + i < n) dst[base + i] = pack_element_f32(src, base + i, q);
+}
+
+// the metadata of conv_pack_weights for dtype f32 (no allocation): kernel family, padded sizes, packed element count
+static int conv_plan_f32(sr_ctx* ctx, int KS, int Cin, int Cout, int rot, ConvWeights* out, PackPlan* plan, int64_t* count) {
     if (KS != 1 && KS != 3 && KS != 5 && KS != 9) return ctx->fail(SR_ERR_INVALID, "conv: kernel size must be 1,3,5 or 9");
     const int E = 4, ntap = KS * KS;
-    ConvWeights w;                                // the metadata of conv_pack_weights for dtype f32
+    ConvWeights w;
     w.dtype = SR_DTYPE_F32; w.KS = KS; w.Cin = Cin; w.Cout = Cout;
     w.CoutP = round_up(Cout, 32);
     const int nb = w.CoutP / 32;
@@ -844,14 +876,78 @@ int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias,
         n = (int64_t)nct * w.nchunks * ntap * w.KGPT * w.NT * 256;
     }
     w.bytes = (size_t)n * 4;
+    *out = w;
+    *plan = PackPlan{layout, ntap, Cin, Cout, w.CinP, w.NT, w.nchunks, w.KGPT, rot, w.CoutP};
+    *count = n;
+    return SR_OK;
+}
+
+int conv_pack_weights_dev(sr_ctx* ctx, const float* d_hwio, const float* d_bias, int KS, int Cin, int Cout, int rot, ConvWeights* out, hipStream_t st) {
+    ConvWeights w;
+    PackPlan plan;
+    int64_t n;
+    const int rc = conv_plan_f32(ctx, KS, Cin, Cout, rot, &w, &plan, &n);
+    if (rc) return rc;
+    if (!ctx->pack_cache.empty()) {                                   // sr_conv_prepack: this use was packed with the step's other weights
+        const auto it = ctx->pack_cache.find(sr_ctx::PackKey{d_hwio, d_bias, KS, Cin, Cout, rot});
+        if (it != ctx->pack_cache.end()) {
+            w.w = it->second.first; w.bias = it->second.second;
+            *out = w;
+            return SR_OK;
+        }
+    }
     w.w = ctx->arena(ctx->dev_w, w.bytes, st);
     w.bias = static_cast<float*>(ctx->arena(ctx->dev_b, sizeof(float) * round_up(w.CoutP, 64), st));
     if (!w.w || !w.bias) return SR_ERR_OOM;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_weights_f32_kernel, dim3(blocks), dim3(256), 0, st, d_hwio, static_cast<float*>(w.w), n, layout, ntap, Cin, Cout, w.CinP,
-                       w.NT, w.nchunks, w.KGPT, rot, d_bias, w.bias, w.CoutP);
+    hipLaunchKernelGGL(pack_weights_f32_kernel, dim3(blocks), dim3(256), 0, st, d_hwio, static_cast<float*>(w.w), n, plan, d_bias, w.bias);
     SR_HIP(ctx, hipGetLastError());
     *out = w;
+    return SR_OK;
+}
+
+int conv_prepack_dev(sr_ctx* ctx, const sr_pack_desc* descs, int n, hipStream_t st) {
+    ctx->pack_cache.clear();                                          // whatever happens below, no stale pack survives this call
+    if (n <= 0) return SR_OK;
+    std::vector<PackJob> jobs((size_t)n);
+    std::vector<sr_ctx::PackKey> keys((size_t)n);
+    size_t wbytes = 0, bbytes = 0;
+    int64_t blocks = 0;
+    std::vector<size_t> woff((size_t)n), boff((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const sr_pack_desc& d = descs[i];
+        if (!d.w || d.Cin <= 0 || d.Cout <= 0) return ctx->fail(SR_ERR_INVALID, "conv prepack: null kernel or bad shape");
+        ConvWeights w;
+        PackJob& jb = jobs[(size_t)i];
+        const int rc = conv_plan_f32(ctx, d.K, d.Cin, d.Cout, d.rot ? 1 : 0, &w, &jb.q, &jb.n);
+        if (rc) return rc;
+        jb.src = d.w; jb.bias = d.bias; jb.blk0 = (int)blocks; jb.pad_ = 0;
+        blocks += (jb.n + PACK_JOB_ELEMS - 1) / PACK_JOB_ELEMS;
+        woff[(size_t)i] = wbytes; boff[(size_t)i] = bbytes;
+        wbytes += (w.bytes + 255) & ~(size_t)255;
+        bbytes += (sizeof(float) * (size_t)round_up(w.CoutP, 64) + 255) & ~(size_t)255;
+        keys[(size_t)i] = sr_ctx::PackKey{d.w, d.bias, d.K, d.Cin, d.Cout, d.rot ? 1 : 0};
+    }
+    if (blocks > 0x7fffffff) return ctx->fail(SR_ERR_INVALID, "conv prepack: too many elements for one launch");
+    char* wb = static_cast<char*>(ctx->arena(ctx->pack_w, wbytes, st));
+    char* bb = static_cast<char*>(ctx->arena(ctx->pack_b, bbytes, st));
+    const size_t tbytes = sizeof(PackJob) * (size_t)n;
+    void* tab = ctx->arena(ctx->pack_tab, tbytes, st);
+    if (!wb || !bb || !tab) return SR_ERR_OOM;
+    for (int i = 0; i < n; ++i) {
+        jobs[(size_t)i].dst = reinterpret_cast<float*>(wb + woff[(size_t)i]);
+        jobs[(size_t)i].bias_out = reinterpret_cast<float*>(bb + boff[(size_t)i]);
+    }
+    // the table is uploaded when it differs from the one on the device (a trainer's list is the same every step: pointers into its parameter bucket)
+    if (ctx->pack_tab_host.size() != tbytes || ctx->pack_tab_dev != tab || memcmp(ctx->pack_tab_host.data(), jobs.data(), tbytes) != 0) {
+        SR_HIP(ctx, hipStreamSynchronize(st));                         // an earlier launch may still be reading the old table
+        SR_HIP(ctx, hipMemcpy(tab, jobs.data(), tbytes, hipMemcpyHostToDevice));
+        ctx->pack_tab_host.assign(reinterpret_cast<const char*>(jobs.data()), reinterpret_cast<const char*>(jobs.data()) + tbytes);
+        ctx->pack_tab_dev = tab;
+    }
+    hipLaunchKernelGGL(pack_weights_f32_many_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const PackJob*>(tab), n);
+    SR_HIP(ctx, hipGetLastError());
+    for (int i = 0; i < n; ++i) ctx->pack_cache[keys[(size_t)i]] = {jobs[(size_t)i].dst, jobs[(size_t)i].bias_out};
     return SR_OK;
 }
 

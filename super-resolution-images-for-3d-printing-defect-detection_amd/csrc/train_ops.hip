@@ -176,21 +176,24 @@ __global__ void __launch_bounds__(256) wgrad3_tile_kernel(const float* x, int64_
 }
 
 __global__ void wgrad_finish_kernel(const float* partial, int ntiles, int nsplit, int Cin, int Cout, int nci, int nco, float* dw, const double* bpart, float* db) {
-    // one thread per element of one 32x32 tile; dw is HWIO [tap][Cin][Cout]
+    // one thread per element of a quarter (blockIdx.y) of one 32x32 tile; dw is HWIO [tap][Cin][Cout].  (Round 4: four elements per thread on a grid of `ntiles`
+    // workgroups -- 45 for a 160 -> 32 conv -- were four dependent rounds of loads on a sixth of the chip: 9 us per conv, 3.3 ms of the cfg3 step.)
     const int tile = blockIdx.x;
     int t = tile;
     const int cob = t % nco; t /= nco;
     const int cib = t % nci;
     const int tap = t / nci;
-    for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+    {
+        const int e = blockIdx.y * 256 + threadIdx.x;
         const int ci = cib * 32 + e / 32, co = cob * 32 + (e & 31);
-        if (ci >= Cin || co >= Cout) continue;
-        float s = 0.f;
+        if (ci < Cin && co < Cout) {
+            float s = 0.f;
 #pragma unroll 16
-        for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * ntiles + tile) * 1024 + e];      // (unrolled: the loads of 16 splits in flight at once)
-        dw[((size_t)tap * Cin + ci) * Cout + co] = s;
+            for (int sp = 0; sp < nsplit; ++sp) s += partial[((size_t)sp * ntiles + tile) * 1024 + e];      // (unrolled: the loads of 16 splits in flight at once)
+            dw[((size_t)tap * Cin + ci) * Cout + co] = s;
+        }
     }
-    if (bpart && db && tap == 0 && cib == 0 && threadIdx.x < 32 && cob * 32 + (int)threadIdx.x < Cout) {      // the tiled kernel's bias-gradient partials
+    if (bpart && db && tap == 0 && cib == 0 && blockIdx.y == 0 && threadIdx.x < 32 && cob * 32 + (int)threadIdx.x < Cout) {      // the tiled kernel's bias-gradient partials
         double t2 = 0.0;
 #pragma unroll 16
         for (int sp = 0; sp < nsplit; ++sp) t2 += bpart[((size_t)sp * nco + cob) * 32 + threadIdx.x];
@@ -500,7 +503,7 @@ int wgrad_launch_views(sr_ctx* ctx, const float* x, int64_t x_cs, const float* d
         if (!partial) return SR_ERR_OOM;
         double* bpart = db ? reinterpret_cast<double*>(reinterpret_cast<char*>(partial) + tile_bytes) : nullptr;
         hipLaunchKernelGGL(wgrad3_tile_kernel, dim3(nci * nco, nsplit), dim3(256), 0, st, x, x_cs, dy, dy_cs, B, H, W, Cin, Cout, nci, nco, tiles_per_wg, tilesX, tilesY, partial, bpart);
-        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, bpart, db);
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles, 4), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, bpart, db);
         SR_HIP(ctx, hipGetLastError());
         return SR_OK;
     }
@@ -510,7 +513,7 @@ int wgrad_launch_views(sr_ctx* ctx, const float* x, int64_t x_cs, const float* d
     float* partial = static_cast<float*>(ctx->scratch((size_t)nsplit * ntiles * 1024 * sizeof(float)));
     if (!partial) return SR_ERR_OOM;
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(ntiles, nsplit), dim3(256), 0, st, x, dy, B, H, W, Cin, Cout, KS, nci, nco, nsplit, partial);
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, (const double*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ntiles, 4), dim3(256), 0, st, partial, ntiles, nsplit, Cin, Cout, nci, nco, dw, (const double*)nullptr, (float*)nullptr);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(Cout), dim3(256), 0, st, dy, P, Cout, db);
     SR_HIP(ctx, hipGetLastError());
     return SR_OK;

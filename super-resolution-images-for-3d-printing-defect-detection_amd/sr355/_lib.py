@@ -30,6 +30,11 @@ class View(C.Structure):
     _fields_ = [("p", C.c_void_p), ("cs", C.c_int64), ("coff", C.c_int32)]
 
 
+class PackDesc(C.Structure):
+    """sr_pack_desc: one conv use whose weights sr_conv_prepack packs (include/sr355.h)."""
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("K", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("rot", C.c_int32)]
+
+
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 _vw = C.POINTER(View)
 _fp = C.POINTER(C.c_float)
@@ -72,6 +77,7 @@ SIGNATURES = {
     "sr_conv2d_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _vp, _f, _i, _i, _vp, _vp]),
     "sr_conv2d_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sr_conv2d_dev_views": (_i, [_vp, _vw, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vw, _f, _vw, _vp]),
+    "sr_conv_prepack": (_i, [_vp, C.POINTER(PackDesc), _i, _vp]),
     "sr_conv2d_wgrad_views": (_i, [_vp, _vw, _vw, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sr_eltwise_views": (_i, [_vp, _i, _vw, _vw, _f, _f, _vw, _i64, _i, _vp]),
     "sr_eltwise": (_i, [_vp, _i, _vp, _vp, _f, _f, _vp, _i64, _vp]),

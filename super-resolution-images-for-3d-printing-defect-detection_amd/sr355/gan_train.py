@@ -370,6 +370,25 @@ class ESRGANTrainer:
         # lies).  With only `allreduce` given the generator's bucket takes the dict route too (the gloo CPU tests).
         self.allreduce, self.allreduce_flat = allreduce, allreduce_flat
         self._last = None
+        self._packs = {}
+
+    def _prepack(self, with_vgg):
+        """Pack every generator (and VGG19) conv's weights for its forward and its input-gradient use by ONE launch (sr_conv_prepack; ~700 of a step's ~800 per-use
+        packs, 3.5 ms of 53).  The discriminator's kernels are renormalised inside the step and keep packing per use.  The list lives until `_unpack`, which every
+        step calls before it returns: nobody else on this context may meet a pack older than the weights."""
+        if with_vgg not in self._packs:
+            uses = []
+            devs = [(self._gw, self._gdev)] + ([(self.vw, self._vggc)] if with_vgg else [])
+            for w, dev in devs:
+                for k, b in w.values():
+                    if getattr(k, "ndim", 0) == 4 and k.shape[0] == k.shape[1] and k.shape[0] in (1, 3) and id(k) in dev and id(b) in dev:
+                        kd, bd = dev[id(k)][1], dev[id(b)][1]
+                        uses += [(kd, bd, False), (kd, None, True)]
+            self._packs[with_vgg] = self.ctx.pack_list(uses)
+        self.ctx.conv_prepack(self._packs[with_vgg])
+
+    def _unpack(self):
+        self.ctx.conv_prepack(None)
 
     @property
     def gw(self):
@@ -477,10 +496,14 @@ class ESRGANTrainer:
         ctx = self.ctx
         lr_t, hr_t = ctx.to_device(np.asarray(lr_images, np.float32)), ctx.to_device(np.asarray(hr_images, np.float32))
         tg = Tape(ctx, self._gw, devcache=dict(self._gdev))
-        y = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att)
-        pix = float(ctx.l1(hr_t, y.v).item())
-        y.g = ctx.eltwise(L.ELT_SIGN_DIFF, y.v, hr_t, 1.0 / y.v.numel(), 0.0)
-        tg.backward()
+        self._prepack(False)
+        try:
+            y = generator_forward(tg, Var(lr_t, need=False), self.scale, self.nb, self.att)
+            pix = float(ctx.l1(hr_t, y.v).item())
+            y.g = ctx.eltwise(L.ELT_SIGN_DIFF, y.v, hr_t, 1.0 / y.v.numel(), 0.0)
+            tg.backward()
+        finally:
+            self._unpack()
         g_flat = self._gather_grads(tg.grads)
         if self.allreduce_flat is not None:
             g_flat = self.allreduce_flat(g_flat)
@@ -492,9 +515,19 @@ class ESRGANTrainer:
 
     def train_step(self, lr_images, hr_images):
         """-> {'g_loss', 'd_loss', parts...}; weights, u, optimiser states advance in place (ESRGAN_model.py:475-533)."""
-        ctx = self.ctx
         if self.dw is None or self.vw is None:
             raise RuntimeError("ESRGANTrainer was built without discriminator / VGG19 weights: only pixel_step is available")
+        if not hasattr(self, "_vggc"):
+            self._vggc = {}                                # the frozen VGG19 stays on the device
+            self._upload(self.vw, self._vggc)
+        self._prepack(True)                                # the generator's weights change only in the step's last line, VGG19's never
+        try:
+            return self._train_step(lr_images, hr_images)
+        finally:
+            self._unpack()
+
+    def _train_step(self, lr_images, hr_images):
+        ctx = self.ctx
         lr_t, hr_t = ctx.to_device(np.asarray(lr_images, np.float32)), ctx.to_device(np.asarray(hr_images, np.float32))
         devc = {}                                          # device copies of this step's parameter arrays (one upload per array)
         if not hasattr(self, "_vggc"):

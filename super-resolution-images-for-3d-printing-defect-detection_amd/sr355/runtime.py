@@ -267,6 +267,30 @@ class Context:
         self.check(self.lib.sr_conv2d_dev_views(self.h, C.byref(xv), B, H, W, int(cin), w_dev.data_ptr(), None if b_dev is None else b_dev.data_ptr(), k, int(cout),
                                                 int(bool(rot)), actc, float(alpha), None if sv is None else C.byref(sv), float(beta1), C.byref(yv), self.stream()))
 
+    def pack_list(self, uses):
+        """uses: [(w_dev [K,K,I,O] fp32 device tensor, b_dev or None, rot)] -> an object for conv_prepack.  rot=False is the layer's forward use (the call's Cin = I,
+        Cout = O, with its bias), rot=True its input-gradient use (Cin = O, Cout = I, no bias) -- exactly the arguments conv2d_dev / conv2d_dev_view pass for them."""
+        arr = (L.PackDesc * max(len(uses), 1))()
+        keep = []
+        for d, (w, b, rot) in zip(arr, uses):
+            _check_tensor(self, w, "pack_list kernel")
+            if b is not None:
+                _check_tensor(self, b, "pack_list bias")
+            k, _, ci, co = w.shape
+            d.w, d.bias, d.K = w.data_ptr(), (None if b is None else b.data_ptr()), k
+            d.Cin, d.Cout, d.rot = (co, ci, 1) if rot else (ci, co, 0)
+            keep.append((w, b))
+        return (arr, len(uses), keep)
+
+    def conv_prepack(self, packed_list):
+        """sr_conv_prepack: pack every listed use by one launch from the weights' CURRENT contents; later conv2d_dev / conv2d_dev_view calls with the same tensors skip
+        their own pack.  Call again after every change of a listed weight; conv_prepack(None) forgets the list."""
+        if packed_list is None:
+            self.check(self.lib.sr_conv_prepack(self.h, None, 0, self.stream()))
+            return
+        arr, n, _ = packed_list
+        self.check(self.lib.sr_conv_prepack(self.h, arr, n, self.stream()))
+
     def conv2d_wgrad_view(self, xbuf, x_coff, cin, dybuf, dy_coff, cout, k):
         """sr_conv2d_wgrad on channel ranges -> (dw HWIO [k,k,cin,cout], db [cout]) device tensors."""
         B, H, W, _ = xbuf.shape

@@ -449,6 +449,60 @@ def test_conv2d_dev_matches_host_packed_conv(ctx, case):
         ctx.conv2d_dev(x, kd, bd, cout + 1)
 
 
+def test_conv_prepack_is_the_per_use_pack(ctx):
+    """sr_conv_prepack (round 4): the weights of a list of conv uses packed by one launch.  Every layout of the fp32 path, forward and input-gradient use, plain and
+    channel-range entry points: the same bytes as a call that packs for itself.  The cache really is what the call reads (a weight changed behind the library's
+    back is NOT seen until the list is packed again or forgotten -- the documented contract, which the trainer honours by packing at the start and forgetting at
+    the end of every step)."""
+    rng = np.random.default_rng(77)
+    cases = [(3, 64, 32), (3, 3, 64), (3, 64, 3), (1, 64, 8), (5, 32, 3), (3, 96, 32), (3, 160, 32), (1, 32, 64), (3, 64, 256)]
+    ws = []
+    for K, cin, cout in cases:
+        k = ctx.to_device((rng.standard_normal((K, K, cin, cout)) / np.sqrt(K * K * cin)).astype(np.float32))
+        b = ctx.to_device(rng.uniform(-0.1, 0.1, cout).astype(np.float32))
+        ws.append((k, b))
+
+    def run():
+        out = []
+        for (K, cin, cout), (k, b) in zip(cases, ws):
+            x = ctx.to_device(np.random.default_rng(cin).standard_normal((2, 13, 11, cin)).astype(np.float32))
+            dy = ctx.to_device(np.random.default_rng(cout).standard_normal((2, 13, 11, cout)).astype(np.float32))
+            out.append(ctx.conv2d_dev(x, k, b, cout, act="relu"))
+            out.append(ctx.conv2d_dev(dy, k, None, cin, rot=True))
+            if cin % 16 == 0 and cout % 32 == 0:
+                buf = ctx.to_device(np.random.default_rng(cin + 1).standard_normal((2, 13, 11, cin + 32)).astype(np.float32))
+                yb = torch.zeros((2, 13, 11, cout + 16), dtype=torch.float32, device=buf.device)
+                ctx.conv2d_dev_view(buf, 16, cin, k, b, cout, yb, 16, act="lrelu")
+                out.append(yb)
+        return out
+
+    base = run()
+    uses = [u for k, b in ws for u in ((k, b, False), (k, None, True))]
+    pl = ctx.pack_list(uses)
+    try:
+        ctx.conv_prepack(pl)
+        for a, c in zip(base, run()):
+            assert torch.equal(a, c)
+        ctx.conv_prepack(pl)                                     # the same list again: the table on the device is reused
+        for a, c in zip(base, run()):
+            assert torch.equal(a, c)
+        ws[0][0].mul_(2.0)                                       # behind the library's back
+        stale = run()
+        assert torch.equal(stale[0], base[0])                    # ... the pack made before the change is what the conv multiplies with
+        ctx.conv_prepack(pl)
+        fresh = run()
+        assert not torch.equal(fresh[0], base[0])                # packed again: the new weights (checked against self-packing calls just below)
+        ctx.conv_prepack(None)
+        for a, c in zip(fresh, run()):                           # forgotten: every call packs for itself again, from the current weights
+            assert torch.equal(a, c)
+        ctx.conv_prepack(ctx.pack_list(uses[:3]))                # a shorter list: the other uses pack for themselves
+        for a, c in zip(fresh, run()):
+            assert torch.equal(a, c)
+    finally:
+        ctx.conv_prepack(None)
+        ws[0][0].mul_(0.5)
+
+
 def test_vgg16_fit_frozen_base(ctx, tmp_path):
     """FineTunedVGG16.fit (VGG16_model.py:111-157) with the default frozen base: conv base on the device per batch, the two Dense
     layers trained on the host.  Without augmentation and dropout the run is deterministic: history and final head against the
