@@ -297,6 +297,9 @@ def main():
     ap.add_argument("--zero-data", action="store_true",
                     help="DIAGNOSTIC, not a result: all-zero weights and tiles -- the same launches with no bit toggling in the operands (MI355X_MICROARCH.md DVFS item 1): what the "
                          "kernels' times become when the chip does not give clock back to data-dependent power; the line says so in `data`")
+    ap.add_argument("--no-zero-step", action="store_true",
+                    help="skip the in-run DVFS diagnostic (one extra pair of steps on all-zero operands): for the rocprofv3 --stats collection, whose per-kernel averages "
+                         "then cover real-data launches only and are directly comparable with roofline.avg_launch_ms")
     ap.add_argument("--no-rows", action="store_true", help="skip the other BASELINE rows (cfg3 training step, cfg4 streaming) that the N = 1 line carries beside the headline")
     ap.add_argument("--fused", type=int, default=511,
                     help="dense-block conv pairs run as one fused kernel: bit 0 conv4+conv5, bit 1 conv2+conv3, bit 2 final_conv2 inside final_conv1, bit 3 attention projections inside the producing conv (0 = layer by layer, for A/B runs)")
@@ -436,7 +439,7 @@ def main():
     # all-zero weights and tiles -- what the dominant kernel's instruction stream sustains when no operand bit toggles and the chip keeps its clock
     zero_prof = None
     res = out.cpu().numpy()                      # the metric sums of the measured steps (the diagnostic below overwrites the device tensor)
-    if not args.no_profile and world == 1 and not args.zero_data and n_mine:
+    if not args.no_profile and world == 1 and not args.zero_data and not args.no_zero_step and n_mine:
         zw = {n: (np.zeros_like(k), np.zeros_like(b)) for n, (k, b) in weights.items()}
         lr_keep = lr
         for m_ in models:

@@ -19,7 +19,7 @@ python3 tools/make_pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" $NDISP 7056 
 python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/${TAG}_pmc_hbm_traffic_b7056.txt" 2>&1 || true
 # the profiled command carries only full-size launches of the hot kernels (no parity patches, no cfg3 / cfg4 rows), so that the per-kernel averages of
 # the stats file are directly the ones bench.py's HIP events report; the complete default line (parity, cpu_baseline, rows) is taken un-profiled below
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-rows --no-parity > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err" || { echo "bench profile failed"; tail -5 "$OUT/bench.err"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-rows --no-parity --no-zero-step > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err" || { echo "bench profile failed"; tail -5 "$OUT/bench.err"; exit 1; }
 tail -1 "$OUT/${TAG}_bench.json" > "$OUT/${TAG}_bench.line" && mv "$OUT/${TAG}_bench.line" "$OUT/${TAG}_bench.json"
 cp "$(find "$OUT/bench" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
 echo "bench + kernel stats done"
