@@ -3,6 +3,9 @@
 //   mode 0: bare v_mfma_f32_16x16x32_bf16, operands in registers, 18 independent accumulators (the dense-block kernels' shape)
 //   mode 1: the same MFMA stream with its operands re-read from LDS by ds_read_b128 in the fused kernels' ratio (30 reads per 54 MFMAs)
 //   mode 2: mode 1 + four loader waves streaming 29 KiB per 54-MFMA granule into LDS by LDS-DMA (11 KiB from HBM, 18 KiB from L2)
+//   mode 6 / 7 (round 4): the same flops on v_mfma_f32_32x32x16_bf16 -- a 32-cout x 32-pixel tile per instruction, HALF the operand bytes (registers and LDS) per flop:
+//           four compute waves (one per SIMD), nine 32 x 32 accumulator tiles each (conv4 + conv5 of two image rows); 6 = bare, 7 = 30 LDS reads per 54 MFMAs + the
+//           loaders' 29 KiB of LDS-DMA + one barrier per granule (what mode 2 is to the kernels as they are, this is to a kernel rebuilt on 32 x 32 tiles)
 // One workgroup per CU (150 KiB of LDS), 8 compute waves (two per SIMD).  Each configuration runs back to back for ~2 s before it is timed;
 // the in-kernel clock is s_memtime / s_memrealtime (100 MHz) over the timed launch.
 #include <hip/hip_runtime.h>
@@ -12,6 +15,7 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -26,7 +30,7 @@ struct P {
 };
 
 template <int MODE>
-__global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 512) k(P p) {
+__global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : (MODE == 6 ? 256 : 512)) k(P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -37,7 +41,41 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 
     __syncthreads();
     unsigned long long t0 = 0, r0 = 0;
     if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    if (MODE == 3 && wave < 4) {
+    if ((MODE == 6 || MODE == 7) && wave < 4) {
+        f32x16 acc[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        const char* base = smem + wave * 4096 + lane * 16;
+        bf16x8 w[4], x[2][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { x[0][j] = *reinterpret_cast<const bf16x8*>(base + 24576 + j * 1024); x[1][j] = *reinterpret_cast<const bf16x8*>(base + 28672 + j * 1024); }
+        for (int it = 0; it < p.iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                if (MODE == 7) {
+                    // one weight fragment per stage (3 stages ahead), three pixel fragments every 4-5 stages: 18 + 12 reads per 54 MFMAs (two rows' worth of pixels)
+                    w[(s + 3) & 3] = *reinterpret_cast<const bf16x8*>(base + (((s + it) & 31) << 10));
+                    if (s == 0 || s == 4 || s == 10 || s == 16) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) x[(s >> 2) & 1][j] = *reinterpret_cast<const bf16x8*>(base + 24576 + (((s + j + it) & 7) << 10));
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt)
+                    acc[(s % 3) * 3 + nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s & 3], x[((s + 2) >> 2) & 1][nt], acc[(s % 3) * 3 + nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sum += acc[j][0] + acc[j][15];
+        if (sum == 12345.678f) p.sink[0] = sum;
+    } else if (MODE == 3 && wave < 4) {
         // one compute wave per SIMD, two image rows per wave: every weight fragment meets six pixel fragments
         f32x4 acc[36];
 #pragma unroll
@@ -72,7 +110,7 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 
 #pragma unroll
         for (int j = 0; j < 36; ++j) sum += acc[j][0] + acc[j][3];
         if (sum == 12345.678f) p.sink[0] = sum;
-    } else if (MODE != 3 && wave < 8) {
+    } else if (MODE != 3 && MODE != 6 && MODE != 7 && wave < 8) {
         f32x4 acc[18];
 #pragma unroll
         for (int j = 0; j < 18; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -116,9 +154,9 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 
 #pragma unroll
         for (int j = 0; j < 18; ++j) sum += acc[j][0] + acc[j][3];
         if (sum == 12345.678f) p.sink[0] = sum;
-    } else if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5) {
+    } else if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7) {
         // loaders: per granule 29 pieces over 4 waves (7-8 each): ~11 from a private HBM stream (nt), ~18 from the shared random buffer (L2)
-        const int lw = wave - (MODE == 3 ? 4 : 8);
+        const int lw = wave - ((MODE == 3 || MODE == 7) ? 4 : 8);
         (void)flags;
         const char* gh = p.hbm + (size_t)blockIdx.x * p.per_wg + (size_t)lw * (p.per_wg / 4) + lane * 16;
         const char* gl = p.rnd + lane * 16;
@@ -177,12 +215,16 @@ int main() {
     const char* names[] = {"bare MFMA, operands in registers", "MFMA + LDS operand reads (30 ds_read_b128 per 54 MFMAs)", "MFMA + LDS reads + 29 KiB of LDS-DMA per granule + one barrier per granule",
                            "4 compute waves (one per SIMD) x two rows: 33 reads per 108 MFMAs, + LDS-DMA + barrier per granule",
                            "mode 2 with the per-granule barrier replaced by a ready / done handshake through LDS counters",
-                           "mode 2 with two barriers per granule and waves 4-7 half a granule behind their SIMD partners (stagger)"};
-    for (int mode = 0; mode < 6; ++mode) {
-        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : mode == 3 ? k<3> : mode == 4 ? k<4> : k<5>;
+                           "mode 2 with two barriers per granule and waves 4-7 half a granule behind their SIMD partners (stagger)",
+                           "bare v_mfma_f32_32x32x16_bf16, 4 waves (one per SIMD) x nine 32x32 tiles, operands in registers",
+                           "32x32x16 MFMAs, 4 compute waves: 30 ds_read_b128 per 54 MFMAs (half of mode 2's per flop) + 29 KiB of LDS-DMA + one barrier per granule"};
+    const int only = getenv("MFMA_MODE") ? atoi(getenv("MFMA_MODE")) : -1;
+    for (int mode = 0; mode < 8; ++mode) {
+        if (only >= 0 && mode != only) continue;
+        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : mode == 3 ? k<3> : mode == 4 ? k<4> : mode == 5 ? k<5> : mode == 6 ? k<6> : k<7>;
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         P p{rnd, hbm, per_wg, stamps, sink, 20000};
-        const int threads = (mode == 2 || mode == 4 || mode == 5) ? 768 : 512;      // mode 3: 4 compute + 4 loader waves
+        const int threads = (mode == 2 || mode == 4 || mode == 5) ? 768 : (mode == 6 ? 256 : 512);      // modes 3, 7: 4 compute + 4 loader waves
         float ms = 0.f, total = 0.f;
         int n = 0;
         while (total < 2500.f && n < 400) {             // ~2.5 s of back-to-back launches, the last one is the measurement
@@ -202,7 +244,7 @@ int main() {
         }
         std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
         const double flop = (double)ncu * 8 * 54.0 * p.iters * 16 * 16 * 32 * 2;      // mode 3: 4 waves x 108 MFMAs = the same
-        const double mfma_per_simd = 2.0 * 54.0 * p.iters;
+        const double mfma_per_simd = 2.0 * 54.0 * p.iters;      // in units of 16-cycle MFMAs (modes 6, 7: one wave per SIMD, 54 32-cycle MFMAs)
         printf("mode %d (%s): %.3f ms, %.1f TFLOP/s, in-kernel clock %.0f MHz (median), %.2f cycles per MFMA per SIMD, pipe utilisation %.3f, %d launches\n", mode, names[mode], ms,
                flop / ms / 1e9, clk[clk.size() / 2], cyc[cyc.size() / 2] / mfma_per_simd, 16.0 * mfma_per_simd / cyc[cyc.size() / 2], n);
         fflush(stdout);
