@@ -3,6 +3,9 @@
 //   mode 0: bare v_mfma_f32_16x16x32_bf16, operands in registers, 18 independent accumulators (the dense-block kernels' shape)
 //   mode 1: the same MFMA stream with its operands re-read from LDS by ds_read_b128 in the fused kernels' ratio (30 reads per 54 MFMAs)
 //   mode 2: mode 1 + four loader waves streaming 29 KiB per 54-MFMA granule into LDS by LDS-DMA (11 KiB from HBM, 18 KiB from L2)
+//   mode 8 (round 4): mode 2 with the kx-shifted pixel fragments made in registers instead of re-read from LDS: 4 instead of 12 pixel-fragment reads per granule, and
+//           72 v_mov_b32_dpp (row_ror:1 of the neighbour column group's fragment, then row_shr:1 of the own one over it) -- what a kernel that walks a chunk's three
+//           kx taps on ONE staging of the rows would issue
 //   mode 6 / 7 (round 4): the same flops on v_mfma_f32_32x32x16_bf16 -- a 32-cout x 32-pixel tile per instruction, HALF the operand bytes (registers and LDS) per flop:
 //           four compute waves (one per SIMD), nine 32 x 32 accumulator tiles each (conv4 + conv5 of two image rows); 6 = bare, 7 = 30 LDS reads per 54 MFMAs + the
 //           loaders' 29 KiB of LDS-DMA + one barrier per granule (what mode 2 is to the kernels as they are, this is to a kernel rebuilt on 32 x 32 tiles)
@@ -30,7 +33,7 @@ struct P {
 };
 
 template <int MODE>
-__global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : (MODE == 6 ? 256 : 512)) k(P p) {
+__global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5 || MODE == 8) ? 768 : (MODE == 6 ? 256 : 512)) k(P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,7 +130,27 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 
 #pragma unroll
             for (int s = 0; s < 18; ++s) {
                 if (MODE == 5 && s == 9) __builtin_amdgcn_s_barrier();      // mid-granule: the partner group's boundary; this wave's reads stay in flight
-                if (MODE >= 1) {
+                if (MODE == 8) {
+                    w[(s + 3) & 3] = *reinterpret_cast<const bf16x8*>(base + (((s + it) & 31) << 10));
+                    if (s == 0) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) x[0][j] = *reinterpret_cast<const bf16x8*>(base + 24576 + (((s + j + it) & 7) << 10));
+                    }
+                    if (s == 10) x[1][0] = *reinterpret_cast<const bf16x8*>(base + 24576 + (((s + it) & 7) << 10));
+                    {
+                        // two dwords of one fragment shifted by a pixel: lane 0 of a 16-lane row from the neighbour column group's lane 15, the rest from the own fragment
+                        typedef int i32x4 __attribute__((ext_vector_type(4)));
+                        i32x4 own = __builtin_bit_cast(i32x4, x[(s >> 2) & 1][s % 3]), nb = __builtin_bit_cast(i32x4, x[(s >> 2) & 1][(s + 2) % 3]);
+                        i32x4 o = __builtin_bit_cast(i32x4, x[((s >> 2) + 1) & 1][s % 3]);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            const int d = 2 * (s & 1) + a;
+                            const int t = __builtin_amdgcn_mov_dpp(nb[d], 0x121, 0xf, 0xf, false);              // row_ror:1
+                            o[d] = __builtin_amdgcn_update_dpp(t, own[d], 0x111, 0xf, 0xf, false);                // row_shr:1, lane 0 keeps t
+                        }
+                        x[((s >> 2) + 1) & 1][s % 3] = __builtin_bit_cast(bf16x8, o);
+                    }
+                } else if (MODE >= 1) {
                     // one weight fragment per stage (3 stages ahead), three pixel fragments every 4-5 stages: 18 + 12 reads per 54 MFMAs
                     w[(s + 3) & 3] = *reinterpret_cast<const bf16x8*>(base + (((s + it) & 31) << 10));
                     if (s == 0 || s == 4 || s == 10 || s == 16) {
@@ -140,7 +163,7 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 
                     acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[s & 3], x[((s + 2) >> 2) & 1][cg], acc[s], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (MODE == 2 || MODE == 5) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+            if (MODE == 2 || MODE == 5 || MODE == 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
             if (MODE == 4) {
                 // done: this wave has finished reading granule `it`; then wait until the loaders have published granule it + 1
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -154,7 +177,7 @@ __global__ void __launch_bounds__((MODE == 2 || MODE == 4 || MODE == 5) ? 768 : 
 #pragma unroll
         for (int j = 0; j < 18; ++j) sum += acc[j][0] + acc[j][3];
         if (sum == 12345.678f) p.sink[0] = sum;
-    } else if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7) {
+    } else if (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 5 || MODE == 7 || MODE == 8) {
         // loaders: per granule 29 pieces over 4 waves (7-8 each): ~11 from a private HBM stream (nt), ~18 from the shared random buffer (L2)
         const int lw = wave - ((MODE == 3 || MODE == 7) ? 4 : 8);
         (void)flags;
@@ -217,14 +240,15 @@ int main() {
                            "mode 2 with the per-granule barrier replaced by a ready / done handshake through LDS counters",
                            "mode 2 with two barriers per granule and waves 4-7 half a granule behind their SIMD partners (stagger)",
                            "bare v_mfma_f32_32x32x16_bf16, 4 waves (one per SIMD) x nine 32x32 tiles, operands in registers",
-                           "32x32x16 MFMAs, 4 compute waves: 30 ds_read_b128 per 54 MFMAs (half of mode 2's per flop) + 29 KiB of LDS-DMA + one barrier per granule"};
+                           "32x32x16 MFMAs, 4 compute waves: 30 ds_read_b128 per 54 MFMAs (half of mode 2's per flop) + 29 KiB of LDS-DMA + one barrier per granule",
+                           "mode 2 with 22 LDS reads per granule and 72 v_mov_b32_dpp making the kx-shifted pixel fragments in registers"};
     const int only = getenv("MFMA_MODE") ? atoi(getenv("MFMA_MODE")) : -1;
-    for (int mode = 0; mode < 8; ++mode) {
+    for (int mode = 0; mode < 9; ++mode) {
         if (only >= 0 && mode != only) continue;
-        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : mode == 3 ? k<3> : mode == 4 ? k<4> : mode == 5 ? k<5> : mode == 6 ? k<6> : k<7>;
+        auto kern = mode == 0 ? k<0> : mode == 1 ? k<1> : mode == 2 ? k<2> : mode == 3 ? k<3> : mode == 4 ? k<4> : mode == 5 ? k<5> : mode == 6 ? k<6> : mode == 7 ? k<7> : k<8>;
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         P p{rnd, hbm, per_wg, stamps, sink, 20000};
-        const int threads = (mode == 2 || mode == 4 || mode == 5) ? 768 : (mode == 6 ? 256 : 512);      // modes 3, 7: 4 compute + 4 loader waves
+        const int threads = (mode == 2 || mode == 4 || mode == 5 || mode == 8) ? 768 : (mode == 6 ? 256 : 512);      // modes 3, 7: 4 compute + 4 loader waves
         float ms = 0.f, total = 0.f;
         int n = 0;
         while (total < 2500.f && n < 400) {             // ~2.5 s of back-to-back launches, the last one is the measurement
