@@ -286,7 +286,10 @@ int build_esrgan(sr_model* m) {
     int cat[3] = {b.buf(CC), b.buf(CC), b.buf(CC)};
     // The concat buffers are only ever touched by convs (written by initial_conv / the dense convs, read by the bf16 3x3
     // kernel): keep them row-blocked so that a 32-channel chunk of a tile row is one contiguous run of whole 128-byte lines.
-    if (m->T == SR_DTYPE_BF16 && G % 32 == 0)
+    // (round 4: any growth width whose concat tensor is a whole number of 32-channel blocks -- the reference's notebook trains G = 8: 96 channels; a growth conv's
+    //  output slice then starts inside a block, which the epilogue's per-lane addressing places)
+    static const bool blk_g32_only = getenv("SR355_BLOCKED_G32_ONLY") != nullptr;       // A/B switch (diagnostic)
+    if (m->T == SR_DTYPE_BF16 && (G % 32 == 0 || (G % 8 == 0 && !blk_g32_only)))
         for (int i = 0; i < 3; ++i) m->bufs[cat[i]].blk = 1;
     Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
     b.conv("initial_conv", 3, C, 64, {x0, 0}, {trunk, 0});

@@ -980,7 +980,8 @@ int conv_launch(sr_ctx* ctx, const ConvWeights& w, TensorView x, int B, int H, i
         else { *cs = v.cs; *ps = 32; *rs = (int)(width * v.cs); }
     };
     for (const TensorView* v : {(const TensorView*)&x, (const TensorView*)&yv, &ep.skip1, &ep.skip2})
-        if (v->p && v->blk && (v->cs % 32 != 0 || v->coff % 32 != 0)) return ctx->fail(SR_ERR_INVALID, "conv: a row-blocked view needs 32-channel granularity");
+        if (v->p && v->blk && (v->cs % 32 != 0 || v->coff % (v == &yv ? 4 : 32) != 0))      // the output may start inside a block (dense blocks of 8 / 16 / 24 growth channels): a lane stores 4 couts, choff() places them
+            return ctx->fail(SR_ERR_INVALID, "conv: a row-blocked view needs 32-channel granularity (4 for the output's first channel)");
     const bool any_blk = x.blk || yv.blk || (ep.skip1.p && ep.skip1.blk) || (ep.skip2.p && ep.skip2.blk);
     if (w.pw && r > 1) return ctx->fail(SR_ERR_INVALID, "conv: 1x1 with depth_to_space is not built");
     if (any_blk && !w.rows) return ctx->fail(SR_ERR_INVALID, "conv: only the bf16 3x3 kernel handles row-blocked views");

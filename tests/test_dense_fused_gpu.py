@@ -224,3 +224,34 @@ def test_two_up_packing_through_the_wrapper(ctx):
     assert np.abs(sr - ref).max() <= 3e-2
     d = abs(float(O.psnr(hr[0], sr, dtype=np.float64)) - float(O.psnr(hr[0], np.clip(ref, 0, 1), dtype=np.float64)))
     assert d <= 0.01, d
+
+
+@pytest.mark.parametrize("growth", [8, 16, 24])
+def test_row_blocked_concat_buffers_at_small_growth_widths(ctx, growth):
+    """Round 4: the concat buffers are row-blocked for every growth width that makes them a whole number of 32-channel blocks (the reference's notebook trains G = 8,
+    ESRGAN.ipynb:L758-761: 96 channels); a growth conv's output slice then STARTS INSIDE a block (channels 64 + 8 k), which the epilogue's per-lane addressing has to
+    place, and a conv reads the whole last block with zero weights on the channels not written yet.  Against the bf16-storage oracle, stage by stage."""
+    nb = 2
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, num_blocks=nb, growth_channels=growth, use_attention=False, ctx=ctx)
+    w = bf16_rounded(init_weights(m.layer_shapes(), seed=3700 + growth))
+    m.set_weights(w)
+    for shape in ((3, 13, 21, 3), (2, 24, 24, 3), (1, 48, 48, 3)):
+        x = round_to_bf16(np.random.default_rng(sum(shape)).uniform(-1, 1, shape).astype(np.float32))
+        xd = ctx.to_device(x, torch.bfloat16)
+        names = ["rrdb_0_dense1_conv1", "rrdb_0_dense1_conv4", "rrdb_0_dense1_conv5", "rrdb_0_dense3_conv5", f"rrdb_{nb - 1}_dense3_conv5", "trunk_conv"]
+        y, taps = m.forward_with_taps(xd, names)
+        assert torch.equal(y, m.forward(xd))                                  # taps do not change the path here (no fused dense-block kernels at these widths)
+        parts = {}
+        ref = M.esrgan_g_forward(x, w, 2, nb, dtype=np.float64, attention=False, bf16_storage=True, parts=parts)
+        for dev, orc in (("rrdb_0_dense3_conv5", "rrdb_0"), (f"rrdb_{nb - 1}_dense3_conv5", f"rrdb_{nb - 1}")):
+            e = rel_l2(taps[dev].cpu().numpy(), parts[orc])
+            assert e <= 5e-3, (shape, dev, e)
+        t1 = taps["rrdb_0_dense1_conv1"].cpu().numpy()
+        assert t1.shape == shape[:3] + (growth,) and (t1 >= 0).all() and t1.max() > 0      # ReLU output of the first growth conv, its own channels only
+        e = rel_l2(y.float().cpu().numpy(), ref)
+        assert e <= 5e-3, (shape, e)
+    # a second forward at another batch reuses the buffers: channels a conv has not written yet hold the previous forward's values, times zero weights
+    x2 = round_to_bf16(np.random.default_rng(5).uniform(-1, 1, (3, 13, 21, 3)).astype(np.float32))
+    y2 = m.forward(ctx.to_device(x2, torch.bfloat16))
+    ref2 = M.esrgan_g_forward(x2, w, 2, nb, dtype=np.float64, attention=False, bf16_storage=True)
+    assert rel_l2(y2.float().cpu().numpy(), ref2) <= 5e-3
