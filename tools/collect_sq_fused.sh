@@ -2,6 +2,7 @@
 # SQ counters of the fused dense-block kernels, two separate --pmc passes over tools/probe_trunk.py 7056 1
 # (rocprofv3 --kernel-trace --pmc only; never combined with other trace domains).  Prints the LAST dispatch of each fused kernel.
 set -o pipefail
+TAG=${1:-r03}
 OUT=gpurun_out/sq_fused
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -14,6 +15,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUS
     echo "## $k"
     python3 tools/pmc_kernel.py "$k" "$OUT/p1" "$OUT/p2"
   done
-} > "$OUT/r03_sq_fused_kernels.txt"
+} > "$OUT/${TAG}_sq_fused_kernels.txt"
 find "$OUT" -name "*.csv" -size +4M -delete
-cat "$OUT/r03_sq_fused_kernels.txt"
+cat "$OUT/${TAG}_sq_fused_kernels.txt"
