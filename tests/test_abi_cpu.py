@@ -85,3 +85,23 @@ def test_fused_mask_default_is_the_same_everywhere():
     bits = re.search(r'"fused_mask_bits": "([^"]*)"', bench).group(1)
     named = [int(t) for t in re.findall(r"(?:^|, )(\d+) ", bits)]
     assert named == [1 << i for i in range(len(named))] and sum(named) == default, (named, default)
+
+
+def test_struct_layouts_of_the_binding_are_the_headers(tmp_path):
+    """sr_view and sr_pack_desc cross the ABI by pointer: the ctypes mirrors in sr355/_lib.py must have the C compiler's sizes and field offsets
+    (a C program that includes the header prints them)."""
+    import subprocess
+    from sr355 import _lib
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sr355.h"\n'
+                   'int main(void) {\n'
+                   '  printf("sr_view %zu %zu %zu %zu\\n", sizeof(sr_view), offsetof(sr_view, p), offsetof(sr_view, cs), offsetof(sr_view, coff));\n'
+                   '  printf("sr_pack_desc %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sr_pack_desc), offsetof(sr_pack_desc, w), offsetof(sr_pack_desc, bias),\n'
+                   '         offsetof(sr_pack_desc, K), offsetof(sr_pack_desc, Cin), offsetof(sr_pack_desc, Cout), offsetof(sr_pack_desc, rot));\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict((l.split()[0], [int(v) for v in l.split()[1:]]) for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    V, P = _lib.View, _lib.PackDesc
+    assert out["sr_view"] == [ctypes.sizeof(V), V.p.offset, V.cs.offset, V.coff.offset]
+    assert out["sr_pack_desc"] == [ctypes.sizeof(P), P.w.offset, P.bias.offset, P.K.offset, P.Cin.offset, P.Cout.offset, P.rot.offset]
