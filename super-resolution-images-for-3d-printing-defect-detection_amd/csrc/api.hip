@@ -123,7 +123,7 @@ struct Op {
     int pw2 = -1;                                   // conv: the next op is the 1x1 conv m->pw2s[pw2], which this fp32 thin conv's epilogue can compute from its accumulators
     int proj = -1;                                  // conv: the next op is the 1x1 projection m->projs[proj], which this conv's epilogue can compute
 };
-struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; int cells = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs); cells: small images may be packed in a CellGrid (common.h)
+struct BufSpec { int C = 0; int mul = 1; int shift = 0; bool vec = false; int Cbuf = 0; int blk = 0; int cshift = 0; int cells = 0; int cat = 0; };   // vec: fp32 [B,C]; blk: row-blocked (conv_common.h); shift: floor halvings (pooling), cshift: ceil halvings (stride-2 SAME convs); cells: small images may be packed in a CellGrid (common.h)
 struct ConvPart { std::string name; int cout; float scale = 1.f; };   // scale: applied to kernel and bias when the conv is packed
 struct ConvSpec { std::vector<ConvPart> parts; int KS = 3, Cin = 0, Cout = 0; ConvWeights w; int rows_head = 0; };   // rows_head: conv_pack_weights
 // two consecutive convs of a dense block that run as ONE kernel when the shape allows (dense_fused.hip): ops[first], ops[first + 1]
@@ -155,6 +155,8 @@ struct sr_model {
     bool finalized = false;
     std::vector<size_t> bufcap;       // bytes currently allocated per workspace buffer (grow-only)
     std::vector<CellGrid> grid_now;   // per workspace buffer: the packed layout its contents have now (gx = 0: plain NHWC)
+    CellGrid cat_grid;                // ESRGAN generator: the cell grid the dense blocks' concat buffers hold now (sr_forward `cellpack`; gx = 0: none / unknown)
+    int cat_dirty = -1;               // ... except this one, which trunk_conv's unpacked input was written to
     struct Tap { float* dst; int64_t cap; };
     std::unordered_map<int, Tap> taps; // diagnostic: op index -> device fp32 destination (sr_model_set_tap)
     std::vector<std::string> op_names; // per op, for sr_model_op_info
@@ -163,7 +165,7 @@ struct sr_model {
         for (size_t i = 0; i < params.size(); ++i) if (params[i].which == which && params[i].name == n) return (int)i;
         return -1;
     }
-    void free_bufs() { for (auto& p : bufp) { if (p) ctx->dfree(p); p = nullptr; } bufcap.assign(bufcap.size(), 0); grid_now.assign(grid_now.size(), CellGrid{}); }
+    void free_bufs() { for (auto& p : bufp) { if (p) ctx->dfree(p); p = nullptr; } bufcap.assign(bufcap.size(), 0); grid_now.assign(grid_now.size(), CellGrid{}); cat_grid = CellGrid{}; cat_dirty = -1; }
 };
 
 namespace {
@@ -291,6 +293,7 @@ int build_esrgan(sr_model* m) {
     static const bool blk_g32_only = getenv("SR355_BLOCKED_G32_ONLY") != nullptr;       // A/B switch (diagnostic)
     if (m->T == SR_DTYPE_BF16 && (G % 32 == 0 || (G % 8 == 0 && !blk_g32_only)))
         for (int i = 0; i < 3; ++i) m->bufs[cat[i]].blk = 1;
+    for (int i = 0; i < 3; ++i) m->bufs[cat[i]].cat = 1;
     Op cv; cv.kind = OP_CONVERT; cv.out = {x0, 0}; m->ops.push_back(cv);
     b.conv("initial_conv", 3, C, 64, {x0, 0}, {trunk, 0});
     if (head_rows) m->convs.back().rows_head = 1;
@@ -893,8 +896,41 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
         const Op& to = m->ops[tp.first];
         if (to.kind == OP_CONV && to.chain >= 0 && m->chains[to.chain].tail && to.chain_pos == 0) pack2 = false;
     }
-    int rc = ensure_workspace(m, pack2 ? (B + 1) & ~1 : B, H, W, st, use_cells);
+    // Cell packing for the dense blocks on the TILE kernels (round 4): where the fused kernels do not apply (another growth width than 32, another width than 48 / two-up 24) and the
+    // images fill the 16 x 16 output tiles badly -- 24 x 24: 56 % -- the concat buffers hold the batch as one image of gx cells per row, (H + 1) x (W + 1) pixels each with a zero
+    // separator row / column (CellGrid): 92 % at 24 x 24.  From the trunk's first concat buffer to trunk_conv's input, as the two-up packing; the convs run on ONE tall image and never
+    // store a separator.
+    CellGrid cp;
+    {
+        static const bool no_cellpack = getenv("SR355_NO_CELLPACK") != nullptr;      // A/B switch (diagnostic)
+        bool cat_blk = false;
+        for (const BufSpec& bs : m->bufs) if (bs.cat && bs.blk) cat_blk = true;
+        const bool fused_here = !m->chains.empty() && W == 48 && (ctx->chain_mask & 3);
+        if (m->kind == SR_MODEL_ESRGAN_G && m->T == SR_DTYPE_BF16 && cat_blk && !pack2 && !fused_here && m->taps.empty() && !no_cellpack && B >= 4 && H >= 2 && W >= 2) {
+            const double plain = (double)H * W / ((double)((H + 15) / 16 * 16) * ((W + 15) / 16 * 16));
+            const int gx = B < 16 ? B : 16;
+            const int64_t Hv = (int64_t)((B + gx - 1) / gx) * (H + 1), Wv = (int64_t)gx * (W + 1);
+            const double packed = (double)B * H * W / ((double)((Hv + 15) / 16 * 16) * ((Wv + 15) / 16 * 16));
+            int Cmax = 0;
+            for (const BufSpec& bs : m->bufs) if (bs.cat) Cmax = std::max(Cmax, bs.Cbuf);
+            if (packed >= 1.15 * plain && Hv * Wv * Cmax < ((int64_t)1 << 31)) { cp.gx = gx; cp.ch = H + 1; cp.cw = W + 1; cp.Hv = (int)Hv; cp.Wv = (int)Wv; }
+        }
+    }
+    const int B_ws = pack2 ? (B + 1) & ~1 : cp.gx ? (int)std::max<int64_t>(B, ((int64_t)cp.Hv * cp.Wv + (int64_t)H * W - 1) / ((int64_t)H * W)) : B;
+    int rc = ensure_workspace(m, B_ws, H, W, st, use_cells);
     if (rc) return rc;
+    if (cp.gx) {
+        // separators (and cells no image has been written to) must be zeros: adopting the grid over other contents clears the buffers; with the grid already in place
+        // only the buffer the last forward unpacked trunk_conv's input into
+        const bool all = !(m->cat_grid == cp);
+        for (size_t i = 0; i < m->bufs.size(); ++i)
+            if (m->bufs[i].cat && (all || (int)i == m->cat_dirty)) SR_HIP(ctx, hipMemsetAsync(m->bufp[i], 0, m->bufcap[i], st));
+        m->cat_grid = cp;
+        m->cat_dirty = -1;
+    } else {
+        m->cat_grid = CellGrid{};                                             // a plain or two-up forward writes where the separators were
+        m->cat_dirty = -1;
+    }
     SR_HIP(ctx, hipEventRecord(ctx->ev0, st));
     const int T = m->T;
     int proj_done = -1;                                                       // index of a 1x1 projection op the previous conv's epilogue has already computed
@@ -944,6 +980,15 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                                : conv1_stream_launch(ctx, cs.w, xin, B, h, w, st);   // conv1 of a dense block: the streaming kernel
                     break;
                 }
+                if (cp.gx && op.pack_alt >= 0) {
+                    // trunk_conv: its input is cell-packed -- unpacked into a free concat buffer first (as for the two-up packing below)
+                    rc = cell_unpack_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.pack_alt], m->bufs[op.pack_alt].Cbuf, 0, cp, st);
+                    if (rc) return rc;
+                    m->cat_dirty = op.pack_alt;                               // that buffer holds a plain image now: the next forward clears it before it packs
+                    xin = TensorView{m->bufp[op.pack_alt], m->bufs[op.pack_alt].Cbuf, 0, m->bufs[op.pack_alt].blk};
+                } else if (cp.gx && m->bufs[op.in.buf].cat && !(op.out.buf >= 0 && m->bufs[op.out.buf].cat)) {
+                    return ctx->fail(SR_ERR_STATE, "cell-packed dense blocks: a conv outside them would read a packed buffer");
+                }
                 if (pack2 && op.pack_alt >= 0) {
                     // trunk_conv: its input, channels [0, 64) of the last dense block's buffer, is two-up packed -- unpacked into a free concat buffer first
                     rc = unpack_pairs_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.pack_alt], m->bufs[op.pack_alt].Cbuf, 0, st);
@@ -990,6 +1035,12 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                         return ctx->fail(SR_ERR_STATE, "packed small-image layout: producer and consumer disagree");
                     cB = 1; h = g.Hv; w = g.Wv; ep.cell_h = g.ch; ep.cell_w = g.cw;
                 }
+                if (cp.gx && op.out.buf >= 0 && m->bufs[op.in.buf].cat && m->bufs[op.out.buf].cat) {
+                    // a dense-block conv on the cell-packed concat buffers: input, output and skips share the grid
+                    if ((op.skip1.buf >= 0 && !m->bufs[op.skip1.buf].cat) || (op.skip2.buf >= 0 && !m->bufs[op.skip2.buf].cat) || op.d2s != 1)
+                        return ctx->fail(SR_ERR_STATE, "cell-packed dense blocks: a skip tensor outside the grid");
+                    cB = 1; h = cp.Hv; w = cp.Wv; ep.cell_h = cp.ch; ep.cell_w = cp.cw;
+                }
                 if (op.skip1.buf >= 0) { ep.skip1 = {m->bufp[op.skip1.buf], m->bufs[op.skip1.buf].Cbuf, op.skip1.coff, m->bufs[op.skip1.buf].blk}; ep.beta1 = op.beta1; }
                 if (op.skip2.buf >= 0) { ep.skip2 = {m->bufp[op.skip2.buf], m->bufs[op.skip2.buf].Cbuf, op.skip2.coff, m->bufs[op.skip2.buf].blk}; ep.beta2 = op.beta2; }
                 if ((ctx->chain_mask & 64) && T == SR_DTYPE_BF16 && oi + 1 < m->ops.size() && m->ops[oi + 1].kind == OP_POOL && m->ops[oi + 1].in.buf == op.out.buf &&
@@ -1030,6 +1081,10 @@ int sr_forward(sr_model* m, const void* x, int io_dtype, int B, int H, int W, in
                 rc = vgg_preproc_launch(ctx, x, io_dtype, (int64_t)B * H * W, m->bufp[op.out.buf], T, m->bufs[op.out.buf].Cbuf, st);
                 break;
             case OP_TOBLK:
+                if (cp.gx) {
+                    rc = cell_pack_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, cp, st);
+                    break;
+                }
                 if (pack2) {
                     rc = pack_pairs_launch(ctx, m->bufp[op.in.buf], m->bufs[op.in.buf].Cbuf, op.in.coff, B, h, w, 64, m->bufp[op.out.buf], m->bufs[op.out.buf].Cbuf, op.out.coff, st);
                     break;

@@ -227,6 +227,8 @@ bool conv1_stream_supported(const ConvWeights& w, const TensorView& in, int W);
 int conv1_stream_launch(sr_ctx* ctx, const ConvWeights& w, TensorView in, int B, int H, int W, hipStream_t st, bool seam = false);
 int pack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, hipStream_t st);
 int unpack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_C, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, hipStream_t st);
+int cell_pack_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, const CellGrid& g, hipStream_t st);
+int cell_unpack_launch(sr_ctx* ctx, const void* src, int64_t src_C, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, const CellGrid& g, hipStream_t st);
 int chain_launch(sr_ctx* ctx, const ChainWeights& w, TensorView in, int B, int H, int W, TensorView out, TensorView skip_o, float alpha, float beta_x,
                  float beta_o, hipStream_t st, bool seam = false);
 

@@ -544,6 +544,60 @@ int unpack_pairs_launch(sr_ctx* ctx, const void* src, int64_t src_C, int src_cof
     return SR_OK;
 }
 
+// Cell packing of small images for the TILE kernels (round 4; api.hip `cellpack`): the batch as ONE image of ceil(B / gx) x gx cells of (H + 1) x (W + 1) pixels, the last row /
+// column of a cell a zero separator (CellGrid, common.h), row-blocked: [Hv][dst_C / 32][Wv][32].  24-pixel-wide images fill 56 % of the 16 x 16 output tiles they are cut into,
+// the grid 92 %.  pack: NHWC channels -> the grid's image pixels (separators and unused cells are zero from the buffer's adoption and never written); unpack: grid -> the
+// ordinary row-blocked layout [B][H][dst_C / 32][W][32].  bf16, 32-channel granularity, one 16-byte unit per thread.
+__global__ void cell_pack_kernel(const bf16_t* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, bf16_t* dst, int64_t dst_C, int dst_coff, int gx, int ch, int cw, int Wv) {
+    const int64_t n = (int64_t)B * H * (C / 32) * W * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(i & 3);
+        int64_t t = i >> 2;
+        const int x = (int)(t % W); t /= W;
+        const int cb = (int)(t % (C / 32)); t /= (C / 32);
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (((int64_t)b * H + y) * W + x) * src_cs + src_coff + cb * 32 + sl * 8);
+        const int64_t row = (int64_t)(b / gx) * ch + y;
+        const int col = (b % gx) * cw + x;
+        *reinterpret_cast<bf16x8*>(dst + row * Wv * dst_C + (int64_t)(dst_coff / 32 + cb) * Wv * 32 + col * 32 + sl * 8) = v;
+    }
+}
+
+__global__ void cell_unpack_kernel(const bf16_t* src, int64_t src_C, int src_coff, int B, int H, int W, int C, bf16_t* dst, int64_t dst_C, int dst_coff, int gx, int ch, int cw, int Wv) {
+    const int64_t n = (int64_t)B * H * (C / 32) * W * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(i & 3);
+        int64_t t = i >> 2;
+        const int x = (int)(t % W); t /= W;
+        const int cb = (int)(t % (C / 32)); t /= (C / 32);
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const int64_t row = (int64_t)(b / gx) * ch + y;
+        const int col = (b % gx) * cw + x;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + row * Wv * src_C + (int64_t)(src_coff / 32 + cb) * Wv * 32 + col * 32 + sl * 8);
+        *reinterpret_cast<bf16x8*>(dst + ((int64_t)b * H + y) * W * dst_C + (int64_t)(dst_coff / 32 + cb) * W * 32 + x * 32 + sl * 8) = v;
+    }
+}
+
+int cell_pack_launch(sr_ctx* ctx, const void* src, int64_t src_cs, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, const CellGrid& g, hipStream_t st) {
+    if (C % 32 || src_coff % 8 || dst_coff % 32 || dst_C % 32 || src_cs % 8 || g.gx < 1 || g.ch != H + 1 || g.cw != W + 1) return ctx->fail(SR_ERR_INVALID, "cell_pack: 32-channel granularity, cells of (H + 1) x (W + 1)");
+    const int64_t n = (int64_t)B * H * (C / 32) * W * 4;
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(cell_pack_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const bf16_t*>(src), src_cs, src_coff, B, H, W, C, static_cast<bf16_t*>(dst), dst_C, dst_coff, g.gx, g.ch, g.cw, g.Wv);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
+int cell_unpack_launch(sr_ctx* ctx, const void* src, int64_t src_C, int src_coff, int B, int H, int W, int C, void* dst, int64_t dst_C, int dst_coff, const CellGrid& g, hipStream_t st) {
+    if (C % 32 || src_coff % 32 || dst_coff % 32 || dst_C % 32 || src_C % 32 || g.gx < 1 || g.ch != H + 1 || g.cw != W + 1) return ctx->fail(SR_ERR_INVALID, "cell_unpack: 32-channel granularity, cells of (H + 1) x (W + 1)");
+    const int64_t n = (int64_t)B * H * (C / 32) * W * 4;
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(cell_unpack_kernel, dim3(grid_for(n)), dim3(256), 0, st, static_cast<const bf16_t*>(src), src_C, src_coff, B, H, W, C, static_cast<bf16_t*>(dst), dst_C, dst_coff, g.gx, g.ch, g.cw, g.Wv);
+    SR_HIP(ctx, hipGetLastError());
+    return SR_OK;
+}
+
 // Diagnostic tap (sr_model_set_tap): channels [coff, coff + C) of an activation buffer -- NHWC or row-blocked, bf16 or fp32 -- as a dense
 // fp32 NHWC tensor.  One thread per element; never on a timed path.
 __global__ void tap_copy_kernel(const void* src, int dtype, int blk, int64_t cs, int coff, int64_t rows, int W, int C, float* dst, int pair_h) {

@@ -266,3 +266,39 @@ def test_row_blocked_concat_buffers_at_small_growth_widths(ctx, growth):
     y2 = m.forward(ctx.to_device(x2, torch.bfloat16))
     ref2 = M.esrgan_g_forward(x2, w, 2, nb, dtype=np.float64, attention=False, bf16_storage=True)
     assert rel_l2(y2.float().cpu().numpy(), ref2) <= 5e-3
+
+
+@pytest.mark.parametrize("growth,shape", [(8, (24, 24)), (32, (24, 24)), (8, (13, 21)), (16, (7, 9)), (8, (24, 40))])
+def test_cell_packed_dense_blocks_on_the_tile_kernels(fused_ctx, growth, shape):
+    """Round 4 (api.hip `cellpack`): where the fused dense-block kernels do not apply and small images fill the 16 x 16 output tiles badly, the concat buffers hold the
+    batch as one image of cells with zero separator rows / columns.  Every output pixel is the same sum in the same order as on the plain layout -- bit for bit the
+    tapped forward's image (a tap switches the packing off) -- and the separators survive changes of batch size, a plain forward in between and the buffer the
+    unpacked trunk input is written to."""
+    ctx = fused_ctx
+    H, W = shape
+    nb = 2
+    m = Model("esrgan_g", compute_dtype="bf16", scale_factor=2, num_blocks=nb, growth_channels=growth, use_attention=False, ctx=ctx)
+    w = bf16_rounded(init_weights(m.layer_shapes(), seed=3800 + growth))
+    m.set_weights(w)
+    ctx.set_fused(ctx.FUSED_ALL & ~35, 0)                                     # G = 32 at 24 wide would otherwise ride two-up on the fused kernels
+
+    def both(B, seed):
+        x = round_to_bf16(np.random.default_rng(seed).uniform(-1, 1, (B, H, W, 3)).astype(np.float32))
+        xd = ctx.to_device(x, torch.bfloat16)
+        y = m.forward(xd)                                                      # cell-packed where it pays (B >= 4)
+        yt, _ = m.forward_with_taps(xd, ["trunk_conv"])                        # plain layout
+        assert torch.equal(y, yt), (B, float((y.float() - yt.float()).abs().max()))
+        assert torch.equal(y, m.forward(xd))
+        return x, y
+
+    x, y = both(37, 1)                                                         # three rows of 16 cells, the last one partly filled
+    ref = M.esrgan_g_forward(x[:6], w, 2, nb, dtype=np.float64, attention=False, bf16_storage=True)
+    assert rel_l2(y[:6].float().cpu().numpy(), ref) <= 5e-3
+    both(5, 2)                                                                 # gx = 5: another grid over the same buffers
+    both(16, 3)
+    both(3, 4)                                                                 # too few images: plain, over the separators
+    both(37, 5)                                                                # ... and the grid again
+    x48 = round_to_bf16(np.random.default_rng(6).uniform(-1, 1, (2, 48, 48, 3)).astype(np.float32))
+    m.forward(ctx.to_device(x48, torch.bfloat16))                              # a plain forward at another size re-allocates / overwrites
+    x2, y2 = both(37, 1)
+    assert torch.equal(y2, y)
